@@ -1,0 +1,257 @@
+/*
+ * vkr_hip_scene.h - C ABI of the MI355X (gfx950) scene-processing library.
+ *
+ * One context owns the HBM-resident scene (hierarchy, local matrices, candidate
+ * rows) of one GPU and runs the per-frame path
+ *     transform propagation -> multi-view sphere frustum cull + ordered
+ *     compaction -> transparent key generation, radix sort, draw emission
+ * entirely on the device. Plain pointers and sizes only; every entry point
+ * returns VKRHIP_OK (0) or a negative error and never aborts.
+ *
+ * All matrices are column-major float[16] (element = m[col*4 + row]), the
+ * reference's Mat4 (lib/src/math/mat.h:214-222). "Vec3" arrays use the
+ * reference's padded 16-byte stride (lib/src/math/vec.h:210-216).
+ *
+ * Threading: one context per host thread, not re-entrant (the reference runs
+ * this path on its render thread only, lib/src/application.h:283).
+ * Ownership: output buffers belong to the context and stay valid until the
+ * next vkrhip_frame() on it, matching the frame-scoped borrow of
+ * VkrWorldPassPayload arrays (lib/src/renderer/vkr_render_packet.h:121-125).
+ *
+ * File:line citations are relative to the reference checkout.
+ */
+#ifndef VKR_HIP_SCENE_H
+#define VKR_HIP_SCENE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKRHIP_OK 0
+#define VKRHIP_ERR_ARG (-1)      /* null/invalid argument or out-of-range size */
+#define VKRHIP_ERR_HIP (-2)      /* a HIP runtime call failed (see vkrhip_last_error) */
+#define VKRHIP_ERR_CAPACITY (-3) /* exceeds a capacity fixed at vkrhip_create */
+#define VKRHIP_ERR_STATE (-4)    /* call order violated (e.g. frame before set_views) */
+
+#define VKRHIP_MAX_VIEWS 64u
+#define VKRHIP_NO_PARENT 0xffffffffu
+#define VKRHIP_PLANE_COUNT 6u  /* LEFT,RIGHT,BOTTOM,TOP,NEAR,FAR: lib/src/math/vkr_frustum.h */
+#define VKRHIP_BUCKET_COUNT 4u /* lib/src/renderer/vkr_gpu_abi.h:14-20 */
+
+/* scene transform flags, lib/src/renderer/systems/vkr_scene_system.h:60-65 */
+#define VKRHIP_DIRTY_LOCAL 0x01u
+#define VKRHIP_DIRTY_WORLD 0x02u
+#define VKRHIP_WORLD_UPDATED 0x08u
+
+/* candidate flags, lib/src/renderer/vkr_render_packet.h:113-118 */
+#define VKRHIP_CAND_BOUNDS_VALID 0x1u
+#define VKRHIP_CAND_CAMERA_OPAQUE 0x2u
+#define VKRHIP_CAND_SHADOW_CASTER 0x4u
+
+/* per-candidate material word (input of vkrhip_set_candidates): bits 0-1 alpha
+ * mode (0 opaque, 1 cutout, 2 blend: lib/src/renderer/resources/vkr_resources.h:129-133),
+ * bit 2 transmissive, bit 3 double sided, bit 4 bounds valid. */
+#define VKRHIP_MAT_ALPHA_MASK 0x3u
+#define VKRHIP_MAT_TRANSMISSIVE 0x4u
+#define VKRHIP_MAT_DOUBLE_SIDED 0x8u
+#define VKRHIP_MAT_BOUNDS_VALID 0x10u
+
+/* vkrhip_frame stage mask */
+#define VKRHIP_STAGE_TRANSFORM 0x1u   /* vkr_scene_update, vkr_scene_system.c:1254-1337 */
+#define VKRHIP_STAGE_CULL 0x2u        /* classify/prefix/encode, deferred.slang:305-420 + application.h:730-806 */
+#define VKRHIP_STAGE_TRANSPARENT 0x4u /* key, sort, emit: application.h:573-587,940-944 */
+#define VKRHIP_STAGE_CANDIDATES 0x8u  /* 144-byte VkrWorldDrawCandidate rows, application.h:617-662 */
+#define VKRHIP_STAGE_WORLD_BOUNDS 0x10u /* instance world spheres, vkr_mesh_manager.c:315-337 */
+#define VKRHIP_STAGE_ALL 0x7u
+
+typedef struct vkrhip_ctx vkrhip_ctx;
+
+typedef struct vkrhip_config {
+  uint32_t struct_size;         /* sizeof(vkrhip_config) */
+  int32_t device;               /* HIP device ordinal */
+  uint64_t max_nodes;           /* scene transform capacity */
+  uint64_t max_candidates;      /* instance x submesh source-row capacity */
+  uint32_t max_views;           /* 1..VKRHIP_MAX_VIEWS */
+  uint32_t partition_capacity;  /* per-view per-bucket cap as command_partition_capacity
+                                   (vkr_vulkan_deferred.c:6-7,289-290); 0 = unlimited */
+  uint64_t visible_capacity;    /* per-view visible list capacity; 0 = max_candidates */
+  uint64_t transparent_capacity;/* sorted blend draw capacity; 0 = max_candidates */
+  uint64_t source_index_base;   /* global index of candidate 0 of this shard */
+  float tie_epsilon;            /* >0: count spheres within eps*max(1,|d|) of a plane */
+  uint32_t flags;               /* reserved, 0 */
+} vkrhip_config;
+
+/* VkrVisibilityStats, lib/src/renderer/vkr_visibility.h:42-46 */
+typedef struct vkrhip_visibility_stats {
+  uint32_t objects_tested;
+  uint32_t objects_culled_camera;
+  uint32_t objects_without_bounds;
+} vkrhip_visibility_stats;
+
+/* VkrGpuDrawCompactionState, lib/src/renderer/vkr_gpu_abi.h:95-103 (80 bytes) */
+typedef struct vkrhip_compaction_state {
+  uint32_t execution_ranges[4][2]; /* {offset, count} per bucket */
+  uint32_t bucket_counts[4];
+  uint32_t bucket_cursors[4];
+  uint32_t visible_count;
+  uint32_t overflow_count;
+  uint32_t resolve_invalid_count;
+  uint32_t occlusion_culled_count;
+} vkrhip_compaction_state;
+
+/* Per-frame scalar results (host copy, valid after vkrhip_get_frame_info). */
+typedef struct vkrhip_frame_info {
+  vkrhip_visibility_stats stats;
+  uint32_t gpu_candidate_count;               /* VkrWorldPassPayload.gpu_candidate_count */
+  uint32_t gpu_camera_opaque_candidate_count; /* application.h:747-748 */
+  uint32_t transmission_gpu_candidate_count;  /* application.h:749 */
+  uint32_t transparent_draw_count;            /* application.h:761, clamped to capacity */
+  uint32_t transparent_overflow;              /* visible blend rows beyond transparent_capacity */
+  uint32_t nodes_updated;                     /* length of the render-dirty list, vkr_scene_system.c:1335 */
+  uint32_t view_count;
+  uint32_t reserved;
+  uint64_t near_plane_ties[VKRHIP_MAX_VIEWS];
+  vkrhip_compaction_state views[VKRHIP_MAX_VIEWS];
+} vkrhip_frame_info;
+
+/* Device-resident outputs of the last frame (HBM pointers on config.device). */
+typedef struct vkrhip_device_outputs {
+  const float *world;               /* max_nodes x 16: SceneTransform.world */
+  const uint8_t *node_flags;        /* max_nodes: SceneTransform.flags after the update */
+  const uint32_t *visible;          /* view v at visible + v*visible_stride: candidate
+                                       indices (+source_index_base), bucket-major, ascending
+                                       inside a bucket; ranges in vkrhip_frame_info.views[v] */
+  uint64_t visible_stride;
+  const uint8_t *transparent_visible; /* n: application.h:714-723,760 */
+  const void *transparent_draws;      /* T x VkrDrawItem (48 B), vkr_render_packet.h:100-111 */
+  const void *transparent_instances;  /* T x VkrInstanceDataGPU (80 B), vkr_gpu_abi.h:34-38 */
+  const uint64_t *transparent_keys;   /* T sort keys, descending (application.h:582-587) */
+  const uint32_t *transparent_source; /* T local candidate indices in draw order */
+  const void *gpu_candidates;         /* n x VkrWorldDrawCandidate (144 B) when STAGE_CANDIDATES ran */
+  const float *world_bounds;          /* n x (cx,cy,cz,r) when STAGE_WORLD_BOUNDS ran */
+  const uint32_t *device_counts;      /* device copy of the scalar counters */
+} vkrhip_device_outputs;
+
+/* ---- lifetime --------------------------------------------------------- */
+int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx);
+void vkrhip_destroy(vkrhip_ctx *ctx);
+/* Message of the last failure on this context (or of vkrhip_create when ctx is NULL). */
+const char *vkrhip_last_error(const vkrhip_ctx *ctx);
+/* Run all work of this context on an existing hipStream_t (NULL restores the
+ * context's own stream). */
+int vkrhip_set_stream(vkrhip_ctx *ctx, void *hip_stream);
+int vkrhip_sync(vkrhip_ctx *ctx);
+
+/* ---- scene state: replaces the SceneTransform column walked by
+ * vkr_scene_update (lib/src/renderer/systems/vkr_scene_system.c:1254-1337) ---
+ * Nodes are stored in the reference's BFS topo order (vkr_scene_system.c:783-833):
+ * level l occupies [level_offsets[l], level_offsets[l+1]) and a node's parent
+ * lies in the level above. vkrhip_levelize() produces this order. */
+int vkrhip_set_hierarchy(vkrhip_ctx *ctx, const uint32_t *parent, uint64_t n_nodes,
+                         const uint64_t *level_offsets, uint32_t levels);
+/* position/rotation(x,y,z,w)/scale, 4 floats each; marks the nodes DIRTY_LOCAL
+ * like the transform setters do. */
+int vkrhip_upload_trs(vkrhip_ctx *ctx, uint64_t first, uint64_t count, const float *pos4,
+                      const float *quat4, const float *scale4);
+/* Cached local matrices (SceneTransform.local); marks the nodes DIRTY_WORLD. */
+int vkrhip_upload_locals(vkrhip_ctx *ctx, uint64_t first, uint64_t count, const float *local16);
+int vkrhip_upload_worlds(vkrhip_ctx *ctx, uint64_t first, uint64_t count, const float *world16);
+int vkrhip_upload_node_flags(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
+                             const uint8_t *flags);
+/* OR `flags` into every node (e.g. VKRHIP_DIRTY_WORLD: everything moved). */
+int vkrhip_mark_all(vkrhip_ctx *ctx, uint8_t flags);
+
+/* ---- candidate source rows: the (instance, submesh) enumeration of
+ * application_build_world_payload (lib/src/application.h:730-806) -----------
+ *   node[i]        transform whose world matrix is the row's model; NULL = i
+ *   ident[i*8..]   mesh.id, mesh.generation, geometry.id, geometry.generation,
+ *                  submesh_index, material.id, material.generation, render_id
+ *   matbits[i]     VKRHIP_MAT_* word
+ *   bounds[i*12..] center, min_extents, max_extents (3 padded Vec3,
+ *                  VkrMeshAssetSubmesh @80..127, vkr_resources.h:292-294) */
+int vkrhip_set_candidates(vkrhip_ctx *ctx, uint64_t n, const uint32_t *node,
+                          const uint32_t *ident, const uint32_t *matbits, const float *bounds);
+
+/* ---- views: camera + cascades as the backend builds them
+ * (lib/src/renderer/vulkan/vkr_vulkan_deferred.c:242-295) --------------------
+ *   planes          V x 6 x (nx,ny,nz,d), from vkrhip_frustum_from_* or the
+ *                   reference's vkr_frustum_from_* (lib/src/math/vkr_frustum.c:33-66)
+ *   required_flags  per view; view 0 = CAMERA_OPAQUE, others SHADOW_CASTER in the reference
+ *   camera_view     the camera view matrix (globals.view) for transparent depth */
+int vkrhip_set_views(vkrhip_ctx *ctx, uint32_t views, const float *planes,
+                     const uint32_t *required_flags, const float *camera_view);
+
+/* ---- the frame ------------------------------------------------------------ */
+/* Enqueues the selected stages on the context's stream and returns without
+ * waiting. */
+int vkrhip_frame(vkrhip_ctx *ctx, uint32_t stages);
+/* Waits for the last frame and copies its scalar results to the host. */
+int vkrhip_get_frame_info(vkrhip_ctx *ctx, vkrhip_frame_info *out);
+int vkrhip_get_device_outputs(vkrhip_ctx *ctx, vkrhip_device_outputs *out);
+
+/* Synchronous device-to-host copies of outputs (after the frame completes). */
+int vkrhip_read_world(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out16);
+int vkrhip_read_locals(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out16);
+int vkrhip_read_node_flags(vkrhip_ctx *ctx, uint64_t first, uint64_t count, uint8_t *out);
+int vkrhip_read_visible(vkrhip_ctx *ctx, uint32_t view, uint64_t count, uint32_t *out);
+int vkrhip_read_transparent_visible(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
+                                    uint8_t *out);
+int vkrhip_read_transparent(vkrhip_ctx *ctx, uint64_t count, void *draws48, void *instances80,
+                            uint64_t *keys, uint32_t *source);
+int vkrhip_read_candidates(vkrhip_ctx *ctx, uint64_t first, uint64_t count, void *rows144);
+int vkrhip_read_world_bounds(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out4);
+int vkrhip_read_candidate_prep(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
+                               float *sphere4, uint32_t *flags_bucket);
+
+/* ---- per-stage device timing (HIP events on the context's stream) ---------- */
+#define VKRHIP_TIMER_TRANSFORM 0
+#define VKRHIP_TIMER_CLASSIFY 1
+#define VKRHIP_TIMER_SCAN 2
+#define VKRHIP_TIMER_SCATTER 3
+#define VKRHIP_TIMER_KEYGEN 4
+#define VKRHIP_TIMER_SORT 5
+#define VKRHIP_TIMER_EMIT 6
+#define VKRHIP_TIMER_CANDIDATES 7
+#define VKRHIP_TIMER_FRAME 8
+#define VKRHIP_TIMER_COUNT 9
+int vkrhip_set_profiling(vkrhip_ctx *ctx, int enabled);
+/* Accumulated milliseconds and sample counts since the last reset; waits for
+ * outstanding work. */
+int vkrhip_get_timers(vkrhip_ctx *ctx, double *ms_out, uint64_t *samples_out, int reset);
+
+/* ---- multi-GPU draw-key merge (no reference counterpart: the reference is
+ * single-GPU; this is the exchange step after an all-gather of per-GPU runs) --
+ * runs_keys/runs_src: `g` device arrays, each sorted descending; lengths on the
+ * host. Writes the merged descending keys and (rank,source) pairs. */
+int vkrhip_merge_runs(vkrhip_ctx *ctx, uint32_t g, const uint64_t *const *runs_keys,
+                      const uint64_t *lengths, uint64_t *out_keys_dev);
+
+/* ---- host-side mirrors of reference leaf functions (exact op order) -------- */
+/* vkr_frustum_from_matrix, lib/src/math/vkr_frustum.c:44-66 */
+void vkrhip_frustum_from_matrix(const float *view_projection, float *planes24);
+/* vkr_frustum_from_view_projection, lib/src/math/vkr_frustum.c:33-38 */
+void vkrhip_frustum_from_view_projection(const float *view, const float *projection,
+                                         float *planes24);
+/* mat4_mul, lib/src/math/mat.h:1145-1163 */
+void vkrhip_mat4_mul(const float *a, const float *b, float *out);
+/* View set of the reference backend (vkr_vulkan_deferred.c:257-273): view 0 from
+ * (view, projection), views 1..cascades from light_view_proj[]. Writes
+ * (1+cascades) x 24 planes and required flags. */
+void vkrhip_build_view_set(const float *view, const float *projection,
+                           const float *light_view_proj, uint32_t cascades, float *planes,
+                           uint32_t *required_flags);
+/* BFS relabelling in the shape of scene_rebuild_topo_order
+ * (vkr_scene_system.c:777-843): order[k] = original index of the node stored at
+ * k; new_parent in the new numbering; level_offsets[levels+1]. Returns levels
+ * (0 on allocation failure). level_offsets must hold n+1 entries at most
+ * (levels <= n). */
+uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
+                         uint32_t *new_parent, uint64_t *level_offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,545 @@
+"""ctypes bindings for the CPU oracle (oracle/libvkr_oracle.so) and, when it was
+built, the compiled reference (oracle/_ref/libvkr_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg. The shipped GPU path never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libvkr_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libvkr_ref.so")
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+vp = C.c_void_p
+
+NO_PARENT = 0xFFFFFFFF
+CULLED = 0xFFFFFFFF
+
+# numpy views of the reference's row layouts (sizes asserted in vkr_oracle.c)
+CANDIDATE_DT = np.dtype(
+    {
+        "names": ["mesh", "geometry", "submesh_index", "material", "model", "object_id",
+                  "reserved", "sphere", "state_bucket", "flags"],
+        "formats": ["2<u4", "2<u4", "<u4", "2<u4", "16<f4", "<u4", "3<u4", "4<f4", "<u4", "<u4"],
+        "offsets": [0, 8, 16, 20, 32, 96, 100, 112, 128, 132],
+        "itemsize": 144,
+    }
+)
+DRAW_DT = np.dtype(
+    {
+        "names": ["mesh", "geometry", "submesh_index", "material", "instance_count",
+                  "first_instance", "sort_key"],
+        "formats": ["2<u4", "2<u4", "<u4", "2<u4", "<u4", "<u4", "<u8"],
+        "offsets": [0, 8, 16, 20, 28, 32, 40],
+        "itemsize": 48,
+    }
+)
+INSTANCE_DT = np.dtype(
+    {
+        "names": ["model", "object_id", "reserved"],
+        "formats": ["16<f4", "<u4", "3<u4"],
+        "offsets": [0, 64, 68],
+        "itemsize": 80,
+    }
+)
+STATE_DT = np.dtype(
+    {
+        "names": ["execution_ranges", "bucket_counts", "bucket_cursors", "visible_count",
+                  "overflow_count", "resolve_invalid_count", "occlusion_culled_count"],
+        "formats": ["(4,2)<u4", "4<u4", "4<u4", "<u4", "<u4", "<u4", "<u4"],
+        "offsets": [0, 32, 48, 64, 68, 72, 76],
+        "itemsize": 80,
+    }
+)
+TRANSPARENT_DT = np.dtype(
+    {
+        "names": ["model", "mesh", "geometry", "material", "submesh_index", "object_id",
+                  "sort_key"],
+        "formats": ["16<f4", "2<u4", "2<u4", "2<u4", "<u4", "<u4", "<u8"],
+        "offsets": [0, 64, 72, 80, 88, 92, 96],
+        "itemsize": 112,
+    }
+)
+GPU_ROW_DT = np.dtype(
+    {
+        "names": ["geometry_index", "material_index", "instance_index", "first_index",
+                  "index_count", "vertex_offset", "state_bucket", "flags", "sphere"],
+        "formats": ["<u4", "<u4", "<u4", "<u4", "<u4", "<i4", "<u4", "<u4", "4<f4"],
+        "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32],
+        "itemsize": 48,
+    }
+)
+VISIBLE_ROW_DT = np.dtype(
+    {
+        "names": ["geometry_index", "material_index", "instance_index", "first_index",
+                  "index_count", "vertex_offset", "state_bucket", "flags"],
+        "formats": ["<u4", "<u4", "<u4", "<u4", "<u4", "<i4", "<u4", "<u4"],
+        "offsets": [0, 4, 8, 12, 16, 20, 24, 28],
+        "itemsize": 32,
+    }
+)
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and the reference shim when /root/reference exists)."""
+    if force or not os.path.exists(ORACLE_SO) or (
+        os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "vkr_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", HERE, os.path.join(HERE, "libvkr_oracle.so")])
+    if os.path.isdir("/root/reference/lib/src") and (force or not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class Oracle:
+    """Array-shaped front end of libvkr_oracle.so."""
+
+    def __init__(self, path: str = ORACLE_SO):
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        L.vko_mat4_mul.argtypes = [f32p, f32p, f32p]
+        L.vko_mat4_mul_vec3.argtypes = [f32p, f32p, f32p]
+        L.vko_mat4_mul_vec4.argtypes = [f32p, f32p, f32p]
+        L.vko_vec3_dot.argtypes = [f32p, f32p]
+        L.vko_vec3_dot.restype = C.c_float
+        L.vko_vec3_length.argtypes = [f32p]
+        L.vko_vec3_length.restype = C.c_float
+        L.vko_quat_to_mat4.argtypes = [f32p, f32p]
+        L.vko_mat4_translate.argtypes = [f32p, f32p]
+        L.vko_mat4_scale.argtypes = [f32p, f32p]
+        L.vko_local_from_trs.argtypes = [f32p, f32p, f32p, f32p]
+        L.vko_mat4_perspective.argtypes = [C.c_float] * 4 + [f32p]
+        L.vko_mat4_ortho_zo_yinv.argtypes = [C.c_float] * 6 + [f32p]
+        L.vko_frustum_from_matrix.argtypes = [f32p, f32p]
+        L.vko_frustum_from_view_projection.argtypes = [f32p, f32p, f32p]
+        L.vko_frustum_test_sphere.argtypes = [f32p, f32p, C.c_float]
+        L.vko_frustum_test_sphere.restype = C.c_int
+        L.vko_submesh_sphere.argtypes = [f32p, f32p, f32p, f32p, f32p, f32p]
+        L.vko_state_bucket.argtypes = [C.c_uint32, C.c_uint32]
+        L.vko_state_bucket.restype = C.c_uint32
+        L.vko_picking_encode_scene_id.argtypes = [C.c_uint32]
+        L.vko_picking_encode_scene_id.restype = C.c_uint32
+        L.vko_transparent_depth.argtypes = [f32p, f32p, f32p]
+        L.vko_transparent_depth.restype = C.c_float
+        L.vko_pack_sort_key.argtypes = [C.c_float, C.c_uint32]
+        L.vko_pack_sort_key.restype = C.c_uint64
+        L.vko_scene_update.argtypes = [vp, C.c_uint64, u32p, C.c_uint64, vp]
+        L.vko_scene_update.restype = C.c_uint64
+        L.vko_build_topo_order.argtypes = [u32p, C.c_uint64, u32p, u32p]
+        L.vko_build_topo_order.restype = C.c_uint32
+        L.vko_transforms_fill.argtypes = [vp, C.c_uint64] + [vp] * 7
+        L.vko_transforms_extract.argtypes = [vp, C.c_uint64, vp, vp, vp]
+        L.vko_instance_world_bounds.argtypes = [f32p, f32p, C.c_float, f32p]
+        L.vko_build_world_payload.argtypes = [
+            f32p, vp, u32p, u32p, f32p, C.c_uint64, f32p, f32p, C.c_uint64, C.c_uint64,
+            vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.vko_build_world_payload.restype = C.c_uint32
+        L.vko_multiview_cull.argtypes = [
+            vp, C.c_uint64, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+            C.c_float, vp, vp, vp, vp]
+        L.vko_multiview_cull_flat.argtypes = [
+            f32p, vp, f32p, u32p, u32p, C.c_uint64, f32p, u32p, C.c_uint32, C.c_uint32,
+            C.c_uint64, C.c_uint64, C.c_float, vp, vp, vp, vp]
+        L.vko_encode_visible_rows.argtypes = [vp, u32p, vp, vp]
+        L.vko_candidate_epoch.argtypes = [vp, C.c_uint32]
+        L.vko_candidate_epoch.restype = C.c_uint64
+        L.vko_merge_runs_desc.argtypes = [vp, u64p, C.c_uint32, u64p]
+        L.vko_baseline_create.argtypes = [
+            C.c_uint64, u32p, f32p, C.c_uint64, vp, u32p, u32p, f32p, C.c_uint32, f32p,
+            u32p, f32p, f32p]
+        L.vko_baseline_create.restype = vp
+        L.vko_baseline_frame.argtypes = [vp]
+        L.vko_baseline_frame.restype = C.c_uint64
+        L.vko_baseline_destroy.argtypes = [vp]
+
+    # ---- leaf math ------------------------------------------------------
+    def mat4_mul(self, a, b):
+        out = np.empty(16, np.float32)
+        self.lib.vko_mat4_mul(_f32(a).reshape(16), _f32(b).reshape(16), out)
+        return out
+
+    def mat4_mul_vec3(self, m, v):
+        out = np.empty(4, np.float32)
+        self.lib.vko_mat4_mul_vec3(_f32(m).reshape(16), _f32(v), out)
+        return out
+
+    def mat4_mul_vec4(self, m, v):
+        out = np.empty(4, np.float32)
+        self.lib.vko_mat4_mul_vec4(_f32(m).reshape(16), _f32(v), out)
+        return out
+
+    def vec3_dot(self, a, b):
+        return np.float32(self.lib.vko_vec3_dot(_f32(a), _f32(b)))
+
+    def vec3_length(self, v):
+        return np.float32(self.lib.vko_vec3_length(_f32(v)))
+
+    def quat_to_mat4(self, q):
+        out = np.empty(16, np.float32)
+        self.lib.vko_quat_to_mat4(_f32(q), out)
+        return out
+
+    def local_from_trs(self, pos, quat, scale):
+        out = np.empty(16, np.float32)
+        self.lib.vko_local_from_trs(_f32(pos), _f32(quat), _f32(scale), out)
+        return out
+
+    def perspective(self, fov, aspect, near, far):
+        out = np.empty(16, np.float32)
+        self.lib.vko_mat4_perspective(fov, aspect, near, far, out)
+        return out
+
+    def ortho_zo_yinv(self, l, r, b, t, n, f):
+        out = np.empty(16, np.float32)
+        self.lib.vko_mat4_ortho_zo_yinv(l, r, b, t, n, f, out)
+        return out
+
+    def frustum_from_matrix(self, vp_):
+        out = np.empty(24, np.float32)
+        self.lib.vko_frustum_from_matrix(_f32(vp_).reshape(16), out)
+        return out
+
+    def frustum_from_view_projection(self, view, proj):
+        out = np.empty(24, np.float32)
+        self.lib.vko_frustum_from_view_projection(_f32(view).reshape(16), _f32(proj).reshape(16), out)
+        return out
+
+    def frustum_test_sphere(self, planes, center, radius):
+        return bool(self.lib.vko_frustum_test_sphere(_f32(planes).reshape(24), _f32(center), radius))
+
+    def submesh_sphere(self, model, center, mn, mx):
+        c = np.empty(3, np.float32)
+        r = np.empty(1, np.float32)
+        self.lib.vko_submesh_sphere(_f32(model).reshape(16), _f32(center), _f32(mn), _f32(mx), c, r)
+        return c, r[0]
+
+    def transparent_key(self, view, model, center, tie_breaker):
+        d = self.lib.vko_transparent_depth(_f32(view).reshape(16), _f32(model).reshape(16), _f32(center))
+        return int(self.lib.vko_pack_sort_key(d, tie_breaker)), np.float32(d)
+
+    def instance_world_bounds(self, model, center, radius):
+        out = np.empty(4, np.float32)
+        self.lib.vko_instance_world_bounds(_f32(model).reshape(16), _f32(center), radius, out)
+        return out
+
+    # ---- scene update ---------------------------------------------------
+    def build_topo_order(self, parent):
+        parent = _u32(parent)
+        n = parent.shape[0]
+        topo = np.empty(n, np.uint32)
+        level = np.empty(n, np.uint32)
+        levels = self.lib.vko_build_topo_order(parent, n, topo, level) if n else 0
+        return topo, level, int(levels)
+
+    def scene_update(self, parent, local=None, world=None, flags=None, pos=None, quat=None,
+                     scale=None, topo=None):
+        """Runs vkr_scene_update once. Returns (local, world, flags, dirty_list)."""
+        parent = _u32(parent)
+        n = parent.shape[0]
+        rec = np.zeros(n * 208, np.uint8)
+
+        def ptr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        keep = []
+        self.lib.vko_transforms_fill(
+            rec.ctypes.data, n, parent.ctypes.data, ptr(pos, np.float32), ptr(quat, np.float32),
+            ptr(scale, np.float32), ptr(local, np.float32), ptr(world, np.float32),
+            ptr(flags, np.uint8))
+        if topo is None:
+            topo, _, _ = self.build_topo_order(parent)
+        topo = _u32(topo)
+        dirty = np.empty(max(n, 1), np.uint32)
+        nd = self.lib.vko_scene_update(rec.ctypes.data, n, topo, topo.shape[0], dirty.ctypes.data)
+        lo = np.empty((n, 16), np.float32)
+        wo = np.empty((n, 16), np.float32)
+        fo = np.empty(n, np.uint8)
+        self.lib.vko_transforms_extract(rec.ctypes.data, n, lo.ctypes.data, wo.ctypes.data,
+                                        fo.ctypes.data)
+        return lo, wo, fo, dirty[:nd].copy()
+
+    # ---- payload --------------------------------------------------------
+    def build_world_payload(self, world, node, ident, matbits, bounds, view, proj, capacity=0,
+                            source_index_base=0):
+        world = _f32(world).reshape(-1, 16)
+        ident = _u32(ident).reshape(-1, 8)
+        n = ident.shape[0]
+        matbits = _u32(matbits)
+        bounds = _f32(bounds).reshape(-1, 12)
+        node_arr = None if node is None else _u32(node)
+        cand = np.zeros(max(n, 1), CANDIDATE_DT)
+        trans = np.zeros(max(n, 1), CANDIDATE_DT)
+        tvis = np.zeros(max(n, 1), np.uint8)
+        draws = np.zeros(max(n, 1), DRAW_DT)
+        inst = np.zeros(max(n, 1), INSTANCE_DT)
+        keys = np.zeros(max(n, 1), np.uint64)
+        src = np.zeros(max(n, 1), np.uint32)
+        stats = np.zeros(3, np.uint32)
+        counts = np.zeros(4, np.uint32)
+        t = self.lib.vko_build_world_payload(
+            world, None if node_arr is None else node_arr.ctypes.data, ident, matbits, bounds, n,
+            _f32(view).reshape(16), _f32(proj).reshape(16), capacity, source_index_base,
+            cand.ctypes.data, trans.ctypes.data, tvis.ctypes.data, draws.ctypes.data,
+            inst.ctypes.data, keys.ctypes.data, src.ctypes.data, stats.ctypes.data,
+            counts.ctypes.data)
+        overflow = capacity and n > capacity
+        return {
+            "gpu_candidates": cand[: 0 if overflow else n],
+            "transmission_candidates": trans[: int(counts[2])],
+            "transparent_visible": tvis[:n],
+            "draws": draws[:t],
+            "instances": inst[:t],
+            "sort_keys": keys[:t],
+            "sorted_source": src[:t],
+            "stats": stats,
+            "counts": counts,
+        }
+
+    def multiview_cull(self, candidates, planes, required_flags, partition_capacity=0,
+                       index_base=0, tie_eps=0.0):
+        n = candidates.shape[0]
+        planes = _f32(planes).reshape(-1, 24)
+        v = planes.shape[0]
+        cls = np.empty((v, max(n, 1)), np.uint32)
+        states = np.zeros(v, STATE_DT)
+        vis = np.full((v, max(n, 1)), 0xFFFFFFFF, np.uint32)
+        ties = np.zeros(v, np.uint64)
+        c = np.ascontiguousarray(candidates)
+        self.lib.vko_multiview_cull(
+            c.ctypes.data, n, planes, _u32(required_flags), v, partition_capacity, max(n, 1),
+            index_base, tie_eps, cls.ctypes.data, states.ctypes.data, vis.ctypes.data,
+            ties.ctypes.data)
+        return cls[:, :n], states, vis[:, :n], ties
+
+    def multiview_cull_flat(self, world, node, sphere4, flags, bucket, planes, required_flags,
+                            partition_capacity=0, index_base=0, tie_eps=0.0):
+        sphere4 = _f32(sphere4).reshape(-1, 4)
+        n = sphere4.shape[0]
+        planes = _f32(planes).reshape(-1, 24)
+        v = planes.shape[0]
+        node_arr = None if node is None else _u32(node)
+        cls = np.empty((v, max(n, 1)), np.uint32)
+        states = np.zeros(v, STATE_DT)
+        vis = np.full((v, max(n, 1)), 0xFFFFFFFF, np.uint32)
+        ties = np.zeros(v, np.uint64)
+        self.lib.vko_multiview_cull_flat(
+            _f32(world).reshape(-1), None if node_arr is None else node_arr.ctypes.data, sphere4,
+            _u32(flags), _u32(bucket), n, planes, _u32(required_flags), v, partition_capacity,
+            max(n, 1), index_base, tie_eps, cls.ctypes.data, states.ctypes.data,
+            vis.ctypes.data, ties.ctypes.data)
+        return cls[:, :n], states, vis[:, :n], ties
+
+    def encode_visible_rows(self, rows, visible, state):
+        rows = np.ascontiguousarray(rows)
+        out = np.zeros(int(state["visible_count"]), VISIBLE_ROW_DT)
+        st = np.ascontiguousarray(state)
+        self.lib.vko_encode_visible_rows(rows.ctypes.data, _u32(visible), st.ctypes.data,
+                                         out.ctypes.data)
+        return out
+
+    def candidate_epoch(self, candidates):
+        c = np.ascontiguousarray(candidates)
+        return int(self.lib.vko_candidate_epoch(c.ctypes.data, c.shape[0]))
+
+    def merge_runs_desc(self, runs):
+        runs = [np.ascontiguousarray(r, dtype=np.uint64) for r in runs]
+        ptrs = (C.c_void_p * len(runs))(*[r.ctypes.data for r in runs])
+        lengths = np.array([r.shape[0] for r in runs], np.uint64)
+        out = np.empty(int(lengths.sum()), np.uint64)
+        self.lib.vko_merge_runs_desc(C.cast(ptrs, vp), lengths, len(runs), out)
+        return out
+
+    # ---- baseline -------------------------------------------------------
+    def baseline_create(self, parent, local, node, ident, matbits, bounds, planes,
+                        required_flags, view, proj):
+        parent = _u32(parent)
+        ident = _u32(ident).reshape(-1, 8)
+        planes = _f32(planes).reshape(-1, 24)
+        node_arr = None if node is None else _u32(node)
+        h = self.lib.vko_baseline_create(
+            parent.shape[0], parent, _f32(local).reshape(-1), ident.shape[0],
+            None if node_arr is None else node_arr.ctypes.data, ident, _u32(matbits),
+            _f32(bounds).reshape(-1), planes.shape[0], planes, _u32(required_flags),
+            _f32(view).reshape(16), _f32(proj).reshape(16))
+        if not h:
+            raise RuntimeError("vko_baseline_create failed")
+        return h
+
+    def baseline_frame(self, h):
+        return int(self.lib.vko_baseline_frame(h))
+
+    def baseline_destroy(self, h):
+        self.lib.vko_baseline_destroy(h)
+
+
+class Reference:
+    """Front end of oracle/_ref/libvkr_ref.so (the reference's own code)."""
+
+    def __init__(self, path: str = REF_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = L = C.CDLL(path)
+        L.ref_layout.argtypes = [u32p]
+        L.ref_mat4_mul.argtypes = [f32p, f32p, f32p]
+        L.ref_mat4_mul_vec3.argtypes = [f32p, f32p, f32p]
+        L.ref_mat4_mul_vec4.argtypes = [f32p, f32p, f32p]
+        L.ref_vec3_dot.argtypes = [f32p, f32p]
+        L.ref_vec3_dot.restype = C.c_float
+        L.ref_vec3_length.argtypes = [f32p]
+        L.ref_vec3_length.restype = C.c_float
+        L.ref_quat_to_mat4.argtypes = [f32p, f32p]
+        L.ref_mat4_translate.argtypes = [f32p, f32p]
+        L.ref_mat4_scale.argtypes = [f32p, f32p]
+        L.ref_mat4_perspective.argtypes = [C.c_float] * 4 + [f32p]
+        L.ref_mat4_ortho_zo_yinv.argtypes = [C.c_float] * 6 + [f32p]
+        L.ref_mat4_look_at.argtypes = [f32p, f32p, f32p, f32p]
+        L.ref_to_radians.argtypes = [C.c_float]
+        L.ref_to_radians.restype = C.c_float
+        L.ref_frustum_from_matrix.argtypes = [f32p, f32p]
+        L.ref_frustum_from_view_projection.argtypes = [f32p, f32p, f32p]
+        L.ref_frustum_test_sphere.argtypes = [f32p, f32p, C.c_float]
+        L.ref_frustum_test_sphere.restype = C.c_int
+        L.ref_submesh_sphere.argtypes = [f32p, f32p, f32p, f32p, f32p, f32p]
+        L.ref_state_bucket.argtypes = [C.c_uint32, C.c_uint32]
+        L.ref_state_bucket.restype = C.c_uint32
+        L.ref_alpha_routing.argtypes = [C.c_uint32, u32p]
+        L.ref_picking_encode_scene.argtypes = [C.c_uint32]
+        L.ref_picking_encode_scene.restype = C.c_uint32
+        L.ref_transparent_sort_emit.argtypes = [vp, C.c_uint32, vp, vp]
+        L.ref_transparent_sort_emit.restype = C.c_uint32
+        L.refc_local_from_trs.argtypes = [f32p, f32p, f32p, f32p]
+        L.refc_propagate.argtypes = [u32p, u32p, C.c_uint64, f32p, f32p]
+        L.refc_transparent_key.argtypes = [f32p, f32p, f32p, C.c_uint32, vp]
+        L.refc_transparent_key.restype = C.c_uint64
+        L.refc_half_extent_length.argtypes = [f32p, f32p]
+        L.refc_half_extent_length.restype = C.c_float
+        L.refc_sphere_visible.argtypes = [f32p, f32p, f32p, f32p]
+        L.refc_sphere_visible.restype = C.c_int
+
+    def layout(self):
+        out = np.zeros(32, np.uint32)
+        self.lib.ref_layout(out)
+        return out
+
+    def mat4_mul(self, a, b):
+        out = np.empty(16, np.float32)
+        self.lib.ref_mat4_mul(_f32(a).reshape(16), _f32(b).reshape(16), out)
+        return out
+
+    def mat4_mul_vec3(self, m, v):
+        out = np.empty(4, np.float32)
+        self.lib.ref_mat4_mul_vec3(_f32(m).reshape(16), _f32(v), out)
+        return out
+
+    def mat4_mul_vec4(self, m, v):
+        out = np.empty(4, np.float32)
+        self.lib.ref_mat4_mul_vec4(_f32(m).reshape(16), _f32(v), out)
+        return out
+
+    def vec3_dot(self, a, b):
+        return np.float32(self.lib.ref_vec3_dot(_f32(a), _f32(b)))
+
+    def vec3_length(self, v):
+        return np.float32(self.lib.ref_vec3_length(_f32(v)))
+
+    def quat_to_mat4(self, q):
+        out = np.empty(16, np.float32)
+        self.lib.ref_quat_to_mat4(_f32(q), out)
+        return out
+
+    def local_from_trs(self, pos, quat, scale):
+        out = np.empty(16, np.float32)
+        self.lib.refc_local_from_trs(_f32(pos), _f32(quat), _f32(scale), out)
+        return out
+
+    def perspective(self, fov, aspect, near, far):
+        out = np.empty(16, np.float32)
+        self.lib.ref_mat4_perspective(fov, aspect, near, far, out)
+        return out
+
+    def ortho_zo_yinv(self, l, r, b, t, n, f):
+        out = np.empty(16, np.float32)
+        self.lib.ref_mat4_ortho_zo_yinv(l, r, b, t, n, f, out)
+        return out
+
+    def look_at(self, eye, center, up):
+        out = np.empty(16, np.float32)
+        self.lib.ref_mat4_look_at(_f32(eye), _f32(center), _f32(up), out)
+        return out
+
+    def to_radians(self, deg):
+        return np.float32(self.lib.ref_to_radians(deg))
+
+    def frustum_from_matrix(self, vp_):
+        out = np.empty(24, np.float32)
+        self.lib.ref_frustum_from_matrix(_f32(vp_).reshape(16), out)
+        return out
+
+    def frustum_from_view_projection(self, view, proj):
+        out = np.empty(24, np.float32)
+        self.lib.ref_frustum_from_view_projection(_f32(view).reshape(16), _f32(proj).reshape(16), out)
+        return out
+
+    def frustum_test_sphere(self, planes, center, radius):
+        return bool(self.lib.ref_frustum_test_sphere(_f32(planes).reshape(24), _f32(center), radius))
+
+    def submesh_sphere(self, model, center, mn, mx):
+        c = np.empty(3, np.float32)
+        r = np.empty(1, np.float32)
+        self.lib.ref_submesh_sphere(_f32(model).reshape(16), _f32(center), _f32(mn), _f32(mx), c, r)
+        return c, r[0]
+
+    def propagate(self, topo, parent, local):
+        local = _f32(local).reshape(-1, 16)
+        world = np.zeros_like(local)
+        self.lib.refc_propagate(_u32(topo), _u32(parent), local.shape[0], local.reshape(-1),
+                                world.reshape(-1))
+        return world
+
+    def transparent_key(self, view, model, center, tie_breaker):
+        d = C.c_float(0)
+        k = self.lib.refc_transparent_key(_f32(view).reshape(16), _f32(model).reshape(16),
+                                          _f32(center), tie_breaker, C.addressof(d))
+        return int(k), np.float32(d.value)
+
+    def half_extent_length(self, mn, mx):
+        return np.float32(self.lib.refc_half_extent_length(_f32(mn), _f32(mx)))
+
+    def sphere_visible(self, model, sphere4, planes):
+        out = np.empty(4, np.float32)
+        v = self.lib.refc_sphere_visible(_f32(model).reshape(16), _f32(sphere4), _f32(planes).reshape(24), out)
+        return bool(v), out
+
+    def transparent_sort_emit(self, candidates):
+        c = np.ascontiguousarray(candidates).copy()
+        n = c.shape[0]
+        draws = np.zeros(max(n, 1), DRAW_DT)
+        inst = np.zeros(max(n, 1), INSTANCE_DT)
+        self.lib.ref_transparent_sort_emit(c.ctypes.data, n, draws.ctypes.data, inst.ctypes.data)
+        return draws[:n], inst[:n]
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_SO)

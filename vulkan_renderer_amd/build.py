@@ -1,0 +1,50 @@
+"""Builds the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libvkrhip.so")
+SOURCES = ["vkrhip.hip", "vkrhip_host.cpp"]
+HEADERS = ["device_math.hpp", "k_transform.hpp", "k_cull.hpp", "k_sort.hpp"]
+
+# -ffp-contract=off: the reference fuses multiply-add only inside mat4_mul
+# (lib/src/math/mat.h:1145-1163); hipcc's default would fuse everywhere and
+# change result bits.
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build libvkrhip.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "vkr_hip_scene.h"))
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

@@ -1,0 +1,478 @@
+// k_cull.hpp - multi-view sphere frustum cull with deterministic, order
+// preserving compaction for gfx950.
+//
+// Semantics: the camera + shadow-cascade classify / prefix / encode passes
+// (lib/src/renderer/shaders/vulkan/slang/world/deferred.slang:225-238,305-420,
+// HZB branch excluded) evaluated with the CPU helpers' arithmetic
+// (lib/src/renderer/vkr_visibility.c:37-50, lib/src/math/vkr_frustum.c:68-84),
+// plus the ordinary-blend camera cull and counters of
+// application_build_world_payload (lib/src/application.h:730-806).
+//
+// Three launches:
+//   k_classify  one thread per candidate; reads world 64 B + sphere 16 B +
+//               flags 4 B once for ALL views (planes are wave-uniform scalar
+//               loads), writes one visibility bit per view and per-tile
+//               survivor counts per (view, bucket) row.
+//   k_scan      exclusive scan of the tile counts of every row, then the
+//               4-bucket prefix of vk_gpu_draw_prefix per view.
+//   k_scatter   re-reads the bit masks (not the matrices) and writes candidate
+//               indices at tile base + wave-ballot rank. Order inside a bucket
+//               is ascending candidate index, one of the orders the
+//               reference's atomics can produce.
+#pragma once
+#include "device_math.hpp"
+
+namespace vkr {
+
+constexpr int CULL_BLOCK = 256;
+constexpr int CULL_ROUNDS = 4;
+constexpr int CULL_TILE = CULL_BLOCK * CULL_ROUNDS;  // candidates per block
+constexpr int CULL_MAX_VIEWS = 64;
+constexpr int CULL_MAX_ROWS = CULL_MAX_VIEWS * 4 + 1;  // (view,bucket) rows + transparent row
+constexpr int MAT_LDS_STRIDE = 5;  // float4 per staged matrix (80 B: conflict-free b128 reads)
+
+// prepared candidate word
+constexpr uint32_t CF_BOUNDS_VALID = 0x1u;    // VKR_WORLD_DRAW_CANDIDATE_BOUNDS_VALID
+constexpr uint32_t CF_CAMERA_OPAQUE = 0x2u;   // VKR_WORLD_DRAW_CANDIDATE_CAMERA_OPAQUE
+constexpr uint32_t CF_SHADOW_CASTER = 0x4u;   // VKR_WORLD_DRAW_CANDIDATE_SHADOW_CASTER
+constexpr uint32_t CF_REF_MASK = 0x7u;
+constexpr uint32_t CF_BUCKET_SHIFT = 4u;      // bits 4..7 state bucket
+constexpr uint32_t CF_BLEND = 0x100u;         // world_transparent
+constexpr uint32_t CF_TRANSMISSIVE = 0x200u;
+
+// device counters (uint32)
+enum : int {
+  CNT_NODES_UPDATED = 0,
+  CNT_WITHOUT_BOUNDS = 1,
+  CNT_CULLED_CAMERA = 2,
+  CNT_CAMERA_OPAQUE = 3,
+  CNT_TRANSMISSION = 4,
+  CNT_TRANSPARENT = 5,        // clamped to capacity
+  CNT_TRANSPARENT_TOTAL = 6,  // before the clamp
+  CNT_COUNT = 8
+};
+
+struct CompactionState {  // VkrGpuDrawCompactionState, vkr_gpu_abi.h:95-103
+  uint32_t execution_ranges[4][2];
+  uint32_t bucket_counts[4];
+  uint32_t bucket_cursors[4];
+  uint32_t visible_count;
+  uint32_t overflow_count;
+  uint32_t resolve_invalid_count;
+  uint32_t occlusion_culled_count;
+};
+static_assert(sizeof(CompactionState) == 80, "VkrGpuDrawCompactionState is 80 bytes");
+
+// ---------------------------------------------------------------------------
+// Candidate preparation (static per scene): application_emit_world_source's
+// flags, state bucket and local sphere (application.h:620-640;
+// vkr_visibility.h:18-39).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare_candidates(const uint32_t *__restrict__ matbits,
+                                                            const float4 *__restrict__ bounds,
+                                                            float4 *__restrict__ sphere,
+                                                            uint32_t *__restrict__ cflags,
+                                                            uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = matbits[i];
+  const uint32_t alpha = m & 0x3u;
+  const bool blend = alpha == 2u;
+  const bool cutout = alpha == 1u;
+  const bool transmissive = (m & 0x4u) != 0;
+  const bool double_sided = (m & 0x8u) != 0;
+  const bool bounds_valid = (m & 0x10u) != 0;
+  const uint32_t bucket = cutout ? (double_sided ? 3u : 2u) : (double_sided ? 1u : 0u);
+  uint32_t f = (bounds_valid ? CF_BOUNDS_VALID : 0u) |
+               ((!transmissive && !blend) ? CF_CAMERA_OPAQUE : 0u) | CF_SHADOW_CASTER;
+  f |= bucket << CF_BUCKET_SHIFT;
+  if (blend) f |= CF_BLEND;
+  if (transmissive) f |= CF_TRANSMISSIVE;
+  const float4 c = bounds[i * 3u + 0];
+  const float4 mn = bounds[i * 3u + 1];
+  const float4 mx = bounds[i * 3u + 2];
+  const float hx = (mx.x - mn.x) * 0.5f;
+  const float hy = (mx.y - mn.y) * 0.5f;
+  const float hz = (mx.z - mn.z) * 0.5f;
+  sphere[i] = make_float4(c.x, c.y, c.z, length3(hx, hy, hz));
+  cflags[i] = f;
+}
+
+struct CullArgs {
+  const float4 *world;     // node matrices, 4 float4 each
+  const uint32_t *node;    // candidate -> node, null = identity
+  const float4 *sphere;    // local sphere per candidate
+  const uint32_t *cflags;  // prepared word per candidate
+  const float4 *planes;    // views x 6
+  const float *tie_eps;    // views x 6: eps * max(1,|d|)
+  const uint32_t *required;
+  uint32_t *masks;         // [word][mask_stride]
+  uint8_t *tvis;           // transparent_visible
+  float4 *world_bounds;    // optional (cx,cy,cz,r) per candidate
+  uint32_t *tile_counts;   // [row][tiles_stride]
+  uint32_t *counters;
+  unsigned long long *ties;  // per view
+  uint64_t n;
+  uint64_t mask_stride;
+  uint64_t tiles_stride;
+  uint32_t views;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Loads the matrices of candidates [base, base+256) for the block: coalesced
+// 16-byte loads staged through LDS when candidate i uses node i, a per-thread
+// gather otherwise.
+template <bool IDENTITY>
+__device__ __forceinline__ Mat4 load_model(const CullArgs &a, float4 *s_mat, uint64_t base,
+                                           uint64_t i, bool valid) {
+  Mat4 m;
+  if (IDENTITY) {
+    const uint32_t t = threadIdx.x;
+    const uint64_t total4 = a.n * 4u;
+    const uint64_t base4 = base * 4u;
+    __syncthreads();  // previous round's readers are done
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t l = t + 256u * (uint32_t)k;  // float4 index inside the tile
+      const uint64_t g = base4 + l;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < total4) v = a.world[g];
+      s_mat[(l >> 2) * MAT_LDS_STRIDE + (l & 3u)] = v;
+    }
+    __syncthreads();
+    const float4 *p = s_mat + t * MAT_LDS_STRIDE;
+    m.c[0] = p[0];
+    m.c[1] = p[1];
+    m.c[2] = p[2];
+    m.c[3] = p[3];
+  } else {
+    if (valid) {
+      const float4 *p = a.world + (uint64_t)a.node[i] * 4u;
+      m.c[0] = p[0];
+      m.c[1] = p[1];
+      m.c[2] = p[2];
+      m.c[3] = p[3];
+    } else {
+      m.c[0] = m.c[1] = m.c[2] = m.c[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  return m;
+}
+
+template <bool IDENTITY, bool TIES, bool BOUNDS_OUT>
+__global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
+  __shared__ float4 s_mat[IDENTITY ? CULL_BLOCK * MAT_LDS_STRIDE : 1];
+  __shared__ uint32_t s_cnt[CULL_MAX_ROWS];
+  __shared__ uint32_t s_stat[4];
+  __shared__ uint32_t s_ties[TIES ? CULL_MAX_VIEWS : 1];
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t rows = a.views * 4u + 1u;
+  for (uint32_t r = t; r < rows; r += CULL_BLOCK) s_cnt[r] = 0u;
+  if (t < 4) s_stat[t] = 0u;
+  if (TIES)
+    for (uint32_t r = t; r < a.views; r += CULL_BLOCK) s_ties[r] = 0u;
+  __syncthreads();
+
+  const uint64_t tile = blockIdx.x;
+  const bool leader = lane_id() == 0;
+  const uint32_t words = (a.views + 31u) >> 5;
+
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t base = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK;
+    if (base >= a.n) break;  // uniform across the block
+    const uint64_t i = base + t;
+    const bool valid = i < a.n;
+    const Mat4 m = load_model<IDENTITY>(a, s_mat, base, i, valid);
+    float4 ls = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t cf = 0xf0u;  // invalid bucket: fails every gate
+    if (valid) {
+      ls = a.sphere[i];
+      cf = a.cflags[i];
+    }
+    // world sphere: vkr_visibility.c:40-49 / deferred.slang:325-333
+    const float3 c = mat4_mul_point(m, ls.x, ls.y, ls.z);
+    const float radius = ls.w * max_basis_length(m);
+    if (BOUNDS_OUT && valid) a.world_bounds[i] = make_float4(c.x, c.y, c.z, radius);
+
+    const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
+    const bool bounds_valid = (cf & CF_BOUNDS_VALID) != 0;
+
+    // ordinary blend rows: application.h:790-803 (camera frustum = view 0 planes)
+    const bool blend_row = valid && (cf & CF_BLEND) && !(cf & CF_TRANSMISSIVE);
+    bool tv = false;
+    if (blend_row) tv = bounds_valid ? sphere_visible(a.planes, c.x, c.y, c.z, radius) : true;
+    if (valid) a.tvis[i] = tv ? 1u : 0u;
+    {
+      const unsigned long long mt = __ballot(tv);
+      const unsigned long long mc = __ballot(blend_row && !tv);
+      const unsigned long long mb = __ballot(valid && !bounds_valid);
+      const unsigned long long mo = __ballot(valid && (cf & CF_CAMERA_OPAQUE));
+      const unsigned long long mx = __ballot(valid && (cf & CF_TRANSMISSIVE));
+      if (leader) {
+        if (mt) atomicAdd(&s_cnt[a.views * 4u], (uint32_t)__popcll(mt));
+        if (mb) atomicAdd(&s_stat[0], (uint32_t)__popcll(mb));
+        if (mc) atomicAdd(&s_stat[1], (uint32_t)__popcll(mc));
+        if (mo) atomicAdd(&s_stat[2], (uint32_t)__popcll(mo));
+        if (mx) atomicAdd(&s_stat[3], (uint32_t)__popcll(mx));
+      }
+    }
+
+    // views: deferred.slang:316-351
+    for (uint32_t w = 0; w < words; ++w) {
+      uint32_t bits = 0u;
+      const uint32_t vend = min(a.views, (w + 1u) * 32u);
+      for (uint32_t v = w * 32u; v < vend; ++v) {
+        const uint32_t req = a.required[v];
+        bool pass = valid && bucket < 4u && (cf & req) == req;
+        bool tie = false;
+        if (pass && bounds_valid) {
+          pass = sphere_visible(a.planes + v * 6u, c.x, c.y, c.z, radius);
+          if (TIES) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+              const float4 pl = a.planes[v * 6u + p];
+              const float dist = dot3(pl.x, pl.y, pl.z, c.x, c.y, c.z) + pl.w;
+              tie = tie || (fabsf(dist + radius) <= a.tie_eps[v * 6u + p]);
+            }
+          }
+        }
+        if (TIES) {
+          const unsigned long long mtie = __ballot(tie);
+          if (leader && mtie) atomicAdd(&s_ties[v], (uint32_t)__popcll(mtie));
+        }
+        if (pass) bits |= 1u << (v & 31u);
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+          const unsigned long long mq = __ballot(pass && bucket == q);
+          if (leader && mq) atomicAdd(&s_cnt[v * 4u + q], (uint32_t)__popcll(mq));
+        }
+      }
+      if (valid) a.masks[(uint64_t)w * a.mask_stride + i] = bits;
+    }
+  }
+  __syncthreads();
+  for (uint32_t r = t; r < rows; r += CULL_BLOCK)
+    a.tile_counts[(uint64_t)r * a.tiles_stride + tile] = s_cnt[r];
+  if (t == 0) {
+    if (s_stat[0]) atomicAdd(&a.counters[CNT_WITHOUT_BOUNDS], s_stat[0]);
+    if (s_stat[1]) atomicAdd(&a.counters[CNT_CULLED_CAMERA], s_stat[1]);
+    if (s_stat[2]) atomicAdd(&a.counters[CNT_CAMERA_OPAQUE], s_stat[2]);
+    if (s_stat[3]) atomicAdd(&a.counters[CNT_TRANSMISSION], s_stat[3]);
+  }
+  if (TIES)
+    for (uint32_t r = t; r < a.views; r += CULL_BLOCK)
+      if (s_ties[r]) atomicAdd(&a.ties[r], (unsigned long long)s_ties[r]);
+}
+
+// ---------------------------------------------------------------------------
+// Block-wide exclusive scan helper (1024 threads, 16 waves).
+// ---------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 1024;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(v, d, 64);
+    if ((int)lane_id() >= d) v += u;
+  }
+  return v;
+}
+
+// Returns the exclusive prefix of `v` over the block and the block total.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave,
+                                                         uint32_t *total) {
+  const uint32_t w = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t inc = wave_inclusive_scan(v);
+  __syncthreads();  // s_wave reuse
+  if (lane_id() == 63) s_wave[w] = inc;
+  __syncthreads();
+  uint32_t wave_base = 0, sum = 0;
+  for (uint32_t k = 0; k < nw; ++k) {
+    const uint32_t x = s_wave[k];
+    if (k < w) wave_base += x;
+    sum += x;
+  }
+  *total = sum;
+  return wave_base + inc - v;
+}
+
+struct ScanArgs {
+  uint32_t *tile_counts;  // [row][tiles_stride], scanned in place
+  CompactionState *states;
+  uint32_t *counters;
+  uint64_t tiles;  // tiles in use this frame
+  uint64_t tiles_stride;
+  uint32_t views;
+  uint32_t partition_capacity;  // 0 = unlimited
+  uint64_t visible_capacity;
+  uint64_t transparent_capacity;
+};
+
+__device__ __forceinline__ uint32_t scan_row(uint32_t *row, uint64_t tiles, uint32_t *s_wave) {
+  uint32_t carry = 0;
+  for (uint64_t base = 0; base < tiles; base += SCAN_BLOCK) {
+    const uint64_t k = base + threadIdx.x;
+    const uint32_t v = k < tiles ? row[k] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, s_wave, &total);
+    if (k < tiles) row[k] = carry + ex;
+    carry += total;
+  }
+  return carry;
+}
+
+// One block per view (vk_gpu_draw_prefix, deferred.slang:354-377) plus one for
+// the transparent row.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
+  __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+  const uint32_t v = blockIdx.x;
+  if (v < a.views) {
+    uint32_t counts[4];
+    for (uint32_t b = 0; b < 4u; ++b)
+      counts[b] = scan_row(a.tile_counts + (uint64_t)(v * 4u + b) * a.tiles_stride, a.tiles, s_wave);
+    if (threadIdx.x == 0) {
+      CompactionState st;
+      uint32_t cursor = 0, overflow = 0;
+      const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
+      for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t count = counts[b];
+        const uint32_t written = count < cap ? count : cap;
+        st.execution_ranges[b][0] = cursor;
+        st.execution_ranges[b][1] = written;
+        st.bucket_counts[b] = count;
+        // every surviving thread of vk_gpu_draw_encode bumps the cursor once
+        st.bucket_cursors[b] = count;
+        cursor += written;
+        overflow += count - written;
+      }
+      st.visible_count = cursor;
+      st.overflow_count = overflow;
+      st.resolve_invalid_count = 0;
+      st.occlusion_culled_count = 0;
+      a.states[v] = st;
+    }
+  } else {
+    const uint32_t total =
+        scan_row(a.tile_counts + (uint64_t)(a.views * 4u) * a.tiles_stride, a.tiles, s_wave);
+    if (threadIdx.x == 0) {
+      const uint64_t cap = a.transparent_capacity;
+      a.counters[CNT_TRANSPARENT_TOTAL] = total;
+      a.counters[CNT_TRANSPARENT] = (uint64_t)total < cap ? total : (uint32_t)cap;
+    }
+  }
+}
+
+struct ScatterArgs {
+  const uint32_t *masks;
+  const uint32_t *cflags;
+  const uint8_t *tvis;
+  const uint32_t *tile_offsets;  // scanned tile counts
+  const CompactionState *states;
+  uint32_t *visible;  // [view][visible_stride]
+  uint32_t *tlist;    // compacted visible blend rows (local candidate indices)
+  uint64_t n;
+  uint64_t mask_stride;
+  uint64_t tiles_stride;
+  uint64_t visible_stride;
+  uint64_t transparent_capacity;
+  uint64_t index_base;
+  uint32_t views;
+  uint32_t partition_capacity;
+};
+
+__global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
+  __shared__ uint32_t s_base[CULL_MAX_ROWS];   // bucket-local index of the tile's first survivor
+  __shared__ uint32_t s_range[CULL_MAX_ROWS];  // execution_ranges[b].x of the row's view
+  __shared__ uint32_t s_wcnt[4][CULL_MAX_ROWS];
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t wave = t >> 6;
+  const uint32_t lane = lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t rows = a.views * 4u + 1u;
+  const uint64_t tile = blockIdx.x;
+  for (uint32_t r = t; r < rows; r += CULL_BLOCK) {
+    s_base[r] = a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
+    s_range[r] = r < a.views * 4u ? a.states[r >> 2].execution_ranges[r & 3u][0] : 0u;
+  }
+  const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
+  const uint32_t words = (a.views + 31u) >> 5;
+
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t base = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK;
+    if (base >= a.n) break;
+    const uint64_t i = base + t;
+    const bool valid = i < a.n;
+    uint32_t cf = 0xf0u;
+    bool tv = false;
+    if (valid) {
+      cf = a.cflags[i];
+      tv = a.tvis[i] != 0;
+    }
+    const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
+
+    // phase 1: per-wave survivor counts per row
+    __syncthreads();  // s_wcnt readers of the previous round are done; s_base visible
+    for (uint32_t w = 0; w < words; ++w) {
+      const uint32_t bits = valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u;
+      const uint32_t vend = min(a.views, (w + 1u) * 32u);
+      for (uint32_t v = w * 32u; v < vend; ++v) {
+        const bool pass = (bits >> (v & 31u)) & 1u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+          const unsigned long long mq = __ballot(pass && bucket == q);
+          if (lane == 0) s_wcnt[wave][v * 4u + q] = (uint32_t)__popcll(mq);
+        }
+      }
+    }
+    {
+      const unsigned long long mt = __ballot(tv);
+      if (lane == 0) s_wcnt[wave][a.views * 4u] = (uint32_t)__popcll(mt);
+    }
+    __syncthreads();
+
+    // phase 2: positions
+    for (uint32_t w = 0; w < words; ++w) {
+      const uint32_t bits = valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u;
+      const uint32_t vend = min(a.views, (w + 1u) * 32u);
+      for (uint32_t v = w * 32u; v < vend; ++v) {
+        const bool pass = (bits >> (v & 31u)) & 1u;
+        const uint32_t row = v * 4u + (bucket & 3u);
+        // lanes of the same bucket among the survivors below this lane
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+          const unsigned long long mb = __ballot(pass && bucket == q);
+          if (bucket == q) rank = (uint32_t)__popcll(mb & lt_mask);
+        }
+        if (pass) {
+          uint32_t local = s_base[row] + rank;
+          for (uint32_t k = 0; k < wave; ++k) local += s_wcnt[k][row];
+          if (local < cap) {
+            const uint64_t slot = (uint64_t)s_range[row] + local;
+            if (slot < a.visible_stride)
+              a.visible[(uint64_t)v * a.visible_stride + slot] = (uint32_t)(a.index_base + i);
+          }
+        }
+      }
+    }
+    {
+      const uint32_t row = a.views * 4u;
+      const unsigned long long mt = __ballot(tv);
+      if (tv) {
+        uint64_t pos = (uint64_t)s_base[row] + (uint32_t)__popcll(mt & lt_mask);
+        for (uint32_t k = 0; k < wave; ++k) pos += s_wcnt[k][row];
+        if (pos < a.transparent_capacity) a.tlist[pos] = (uint32_t)i;
+      }
+    }
+    __syncthreads();
+    // advance the tile-local running base by this round's survivors
+    for (uint32_t r = t; r < rows; r += CULL_BLOCK)
+      s_base[r] += s_wcnt[0][r] + s_wcnt[1][r] + s_wcnt[2][r] + s_wcnt[3][r];
+  }
+}
+
+}  // namespace vkr

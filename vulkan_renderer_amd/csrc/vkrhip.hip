@@ -1,0 +1,1011 @@
+// vkrhip.hip - C ABI of the gfx950 scene-processing library: context, HBM
+// buffers, uploads, the per-frame launch sequence and result read-back.
+// Entry points are declared (with the reference interfaces they stand behind)
+// in include/vkr_hip_scene.h.
+#include "../../include/vkr_hip_scene.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_math.hpp"
+#include "k_cull.hpp"
+#include "k_sort.hpp"
+#include "k_transform.hpp"
+
+using namespace vkr;
+
+static_assert(sizeof(vkrhip_compaction_state) == sizeof(CompactionState), "state ABI");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t start, stop;
+  int timer;
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t count = 0;
+};
+
+}  // namespace
+
+struct vkrhip_ctx {
+  vkrhip_config cfg{};
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // scene
+  uint64_t n_nodes = 0;
+  std::vector<uint64_t> level_offsets;
+  DevBuf<uint32_t> parent;
+  DevBuf<float4> pos, quat, scale;  // lazily allocated
+  DevBuf<float4> local, world;
+  DevBuf<uint8_t> flags;
+  uint32_t force_flags = 0;
+  bool have_trs = false;
+
+  // candidates
+  uint64_t n_cand = 0;
+  bool node_identity = true;
+  DevBuf<uint32_t> node;
+  DevBuf<uint4> ident;
+  DevBuf<float4> sphere;
+  DevBuf<uint32_t> cflags;
+  uint64_t blend_rows = 0;  // rows that can enter the transparent list
+  uint64_t tcap = 0;        // allocated transparent capacity
+
+  // views
+  uint32_t views = 0;
+  DevBuf<float4> planes;
+  DevBuf<float> tie_eps;
+  DevBuf<uint32_t> required;
+  DevBuf<float4> camera_view;
+
+  // cull intermediates / outputs
+  uint32_t mask_words = 0;
+  uint64_t tiles_stride = 0;
+  DevBuf<uint32_t> masks;
+  DevBuf<uint8_t> tvis;
+  DevBuf<uint32_t> tile_counts;
+  DevBuf<CompactionState> states;
+  DevBuf<uint32_t> counters;
+  DevBuf<unsigned long long> ties;
+  DevBuf<uint32_t> visible;
+  uint64_t visible_stride = 0;
+  DevBuf<float4> world_bounds;
+  DevBuf<uint4> cand_rows;
+
+  // transparent
+  DevBuf<uint32_t> tlist;
+  DevBuf<uint64_t> keys_a, keys_b, out_keys;
+  DevBuf<uint32_t> vals_a, vals_b, out_source;
+  DevBuf<uint32_t> hist;
+  uint32_t sort_tiles_stride = 0;
+  DevBuf<uint4> draws;
+  DevBuf<float4> instances;
+  bool sorted_in_a = true;
+
+  // merge scratch
+  DevBuf<const uint64_t *> merge_ptrs;
+  DevBuf<uint64_t> merge_lens;
+
+  // timing
+  bool profiling = false;
+  std::vector<EventPair> pending;
+  std::vector<EventPair> free_events;
+  double timer_ms[VKRHIP_TIMER_COUNT] = {};
+  uint64_t timer_n[VKRHIP_TIMER_COUNT] = {};
+
+  bool frame_ran = false;
+  uint32_t last_stages = 0;
+};
+
+namespace {
+
+int fail(vkrhip_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((c), VKRHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+template <typename T>
+int dev_alloc(vkrhip_ctx *c, DevBuf<T> &b, size_t count) {
+  if (b.p && b.count >= count) return VKRHIP_OK;
+  if (b.p) {
+    HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.count = 0;
+  }
+  if (count == 0) count = 1;
+  HIP_TRY(c, hipMalloc((void **)&b.p, count * sizeof(T)));
+  b.count = count;
+  return VKRHIP_OK;
+}
+
+template <typename T>
+void dev_free(DevBuf<T> &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.count = 0;
+}
+
+int bind_device(vkrhip_ctx *c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return VKRHIP_OK;
+}
+
+#define TRY(expr)                    \
+  do {                               \
+    int r_ = (expr);                 \
+    if (r_ != VKRHIP_OK) return r_;  \
+  } while (0)
+
+// Timer scope: records an event pair around a stage when profiling is on.
+struct StageTimer {
+  vkrhip_ctx *c;
+  EventPair ev{};
+  bool on = false;
+  StageTimer(vkrhip_ctx *ctx, int timer) : c(ctx) {
+    if (!c->profiling) return;
+    if (!c->free_events.empty()) {
+      ev = c->free_events.back();
+      c->free_events.pop_back();
+    } else {
+      if (hipEventCreate(&ev.start) != hipSuccess) return;
+      if (hipEventCreate(&ev.stop) != hipSuccess) {
+        (void)hipEventDestroy(ev.start);
+        return;
+      }
+    }
+    ev.timer = timer;
+    on = hipEventRecord(ev.start, c->stream) == hipSuccess;
+    if (!on) c->free_events.push_back(ev);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    (void)hipEventRecord(ev.stop, c->stream);
+    c->pending.push_back(ev);
+  }
+};
+
+int drain_timers(vkrhip_ctx *c) {
+  for (const EventPair &ev : c->pending) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventSynchronize(ev.stop));
+    HIP_TRY(c, hipEventElapsedTime(&ms, ev.start, ev.stop));
+    c->timer_ms[ev.timer] += ms;
+    c->timer_n[ev.timer] += 1;
+    c->free_events.push_back(ev);
+  }
+  c->pending.clear();
+  return VKRHIP_OK;
+}
+
+uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+int check_range(vkrhip_ctx *c, uint64_t first, uint64_t count, uint64_t limit, const char *what) {
+  if (first > limit || count > limit - first)
+    return fail(c, VKRHIP_ERR_ARG, "%s: range [%llu, +%llu) exceeds %llu", what,
+                (unsigned long long)first, (unsigned long long)count, (unsigned long long)limit);
+  return VKRHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vkrhip_last_error(const vkrhip_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
+  if (!out_ctx) return fail(nullptr, VKRHIP_ERR_ARG, "out_ctx is null");
+  *out_ctx = nullptr;
+  if (!config || config->struct_size != sizeof(vkrhip_config))
+    return fail(nullptr, VKRHIP_ERR_ARG, "config is null or struct_size mismatch");
+  if (config->max_views == 0 || config->max_views > VKRHIP_MAX_VIEWS)
+    return fail(nullptr, VKRHIP_ERR_ARG, "max_views must be 1..%u", VKRHIP_MAX_VIEWS);
+  if (config->max_nodes == 0 || config->max_nodes > 0xfffffffeull ||
+      config->max_candidates > 0xfffffffeull)
+    return fail(nullptr, VKRHIP_ERR_ARG, "max_nodes/max_candidates must be 1..2^32-2");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, VKRHIP_ERR_HIP, "no HIP device available");
+  if (config->device < 0 || config->device >= ndev)
+    return fail(nullptr, VKRHIP_ERR_ARG, "device %d out of range (0..%d)", config->device, ndev - 1);
+  vkrhip_ctx *c = new (std::nothrow) vkrhip_ctx();
+  if (!c) return fail(nullptr, VKRHIP_ERR_HIP, "out of host memory");
+  c->cfg = *config;
+  c->device = config->device;
+  if (c->cfg.visible_capacity == 0) c->cfg.visible_capacity = c->cfg.max_candidates;
+  if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
+  int rc = VKRHIP_OK;
+  auto run = [&]() -> int {
+    TRY(bind_device(c));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
+    TRY(dev_alloc(c, c->local, mn * 4));
+    TRY(dev_alloc(c, c->world, mn * 4));
+    TRY(dev_alloc(c, c->flags, mn + 16));
+    HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, mn + 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->world.p, 0, mn * 64, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->local.p, 0, mn * 64, c->stream));
+    TRY(dev_alloc(c, c->ident, mc * 2));
+    TRY(dev_alloc(c, c->sphere, mc));
+    TRY(dev_alloc(c, c->cflags, mc));
+    TRY(dev_alloc(c, c->planes, VKRHIP_MAX_VIEWS * 6));
+    TRY(dev_alloc(c, c->tie_eps, VKRHIP_MAX_VIEWS * 6));
+    TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
+    TRY(dev_alloc(c, c->camera_view, 4));
+    c->mask_words = (c->cfg.max_views + 31u) / 32u;
+    c->tiles_stride = ceil_div(mc, CULL_TILE);
+    TRY(dev_alloc(c, c->masks, (size_t)c->mask_words * mc));
+    TRY(dev_alloc(c, c->tvis, mc));
+    TRY(dev_alloc(c, c->tile_counts, (size_t)(c->cfg.max_views * 4u + 1u) * c->tiles_stride));
+    TRY(dev_alloc(c, c->states, VKRHIP_MAX_VIEWS));
+    TRY(dev_alloc(c, c->counters, CNT_COUNT));
+    TRY(dev_alloc(c, c->ties, VKRHIP_MAX_VIEWS));
+    HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * CNT_COUNT, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ties.p, 0, sizeof(unsigned long long) * VKRHIP_MAX_VIEWS, c->stream));
+    c->visible_stride = c->cfg.visible_capacity;
+    TRY(dev_alloc(c, c->visible, (size_t)c->cfg.max_views * c->visible_stride));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VKRHIP_OK;
+  };
+  rc = run();
+  if (rc != VKRHIP_OK) {
+    g_create_error = c->err;
+    vkrhip_destroy(c);
+    return rc;
+  }
+  *out_ctx = c;
+  return VKRHIP_OK;
+}
+
+void vkrhip_destroy(vkrhip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (EventPair &ev : c->pending) {
+    (void)hipEventDestroy(ev.start);
+    (void)hipEventDestroy(ev.stop);
+  }
+  for (EventPair &ev : c->free_events) {
+    (void)hipEventDestroy(ev.start);
+    (void)hipEventDestroy(ev.stop);
+  }
+  dev_free(c->parent);
+  dev_free(c->pos);
+  dev_free(c->quat);
+  dev_free(c->scale);
+  dev_free(c->local);
+  dev_free(c->world);
+  dev_free(c->flags);
+  dev_free(c->node);
+  dev_free(c->ident);
+  dev_free(c->sphere);
+  dev_free(c->cflags);
+  dev_free(c->planes);
+  dev_free(c->tie_eps);
+  dev_free(c->required);
+  dev_free(c->camera_view);
+  dev_free(c->masks);
+  dev_free(c->tvis);
+  dev_free(c->tile_counts);
+  dev_free(c->states);
+  dev_free(c->counters);
+  dev_free(c->ties);
+  dev_free(c->visible);
+  dev_free(c->world_bounds);
+  dev_free(c->cand_rows);
+  dev_free(c->tlist);
+  dev_free(c->keys_a);
+  dev_free(c->keys_b);
+  dev_free(c->out_keys);
+  dev_free(c->vals_a);
+  dev_free(c->vals_b);
+  dev_free(c->out_source);
+  dev_free(c->hist);
+  dev_free(c->draws);
+  dev_free(c->instances);
+  dev_free(c->merge_ptrs);
+  dev_free(c->merge_lens);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int vkrhip_set_stream(vkrhip_ctx *c, void *hip_stream) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return VKRHIP_OK;
+}
+
+int vkrhip_sync(vkrhip_ctx *c) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// scene state
+// ---------------------------------------------------------------------------
+int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes,
+                         const uint64_t *level_offsets, uint32_t levels) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if (n_nodes > c->cfg.max_nodes)
+    return fail(c, VKRHIP_ERR_CAPACITY, "n_nodes %llu exceeds max_nodes %llu",
+                (unsigned long long)n_nodes, (unsigned long long)c->cfg.max_nodes);
+  if (levels == 0 && n_nodes != 0) return fail(c, VKRHIP_ERR_ARG, "levels is 0");
+  if (n_nodes && !level_offsets) return fail(c, VKRHIP_ERR_ARG, "level_offsets is null");
+  if (levels > 1 && !parent) return fail(c, VKRHIP_ERR_ARG, "parent is null with %u levels", levels);
+  std::vector<uint64_t> lo;
+  if (n_nodes) {
+    lo.assign(level_offsets, level_offsets + levels + 1);
+    if (lo[0] != 0 || lo[levels] != n_nodes)
+      return fail(c, VKRHIP_ERR_ARG, "level_offsets must start at 0 and end at n_nodes");
+    for (uint32_t l = 0; l < levels; ++l)
+      if (lo[l] > lo[l + 1]) return fail(c, VKRHIP_ERR_ARG, "level_offsets not ascending");
+    // every node's parent must sit in an earlier level: the level launches
+    // rely on it both for correctness and for memory safety
+    if (parent) {
+      for (uint32_t l = 0; l < levels; ++l) {
+        for (uint64_t i = lo[l]; i < lo[l + 1]; ++i) {
+          const uint32_t p = parent[i];
+          if (p == VKRHIP_NO_PARENT) continue;
+          if (l == 0 || p >= lo[l])
+            return fail(c, VKRHIP_ERR_ARG, "node %llu (level %u) has parent %u outside earlier levels",
+                        (unsigned long long)i, l, p);
+        }
+      }
+    }
+  }
+  TRY(bind_device(c));
+  if (parent && n_nodes) {
+    TRY(dev_alloc(c, c->parent, c->cfg.max_nodes));
+    HIP_TRY(c, hipMemcpyAsync(c->parent.p, parent, n_nodes * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->n_nodes = n_nodes;
+  c->level_offsets = lo;
+  return VKRHIP_OK;
+}
+
+int vkrhip_upload_trs(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *pos4,
+                      const float *quat4, const float *scale4) {
+  if (!c || !pos4 || !quat4 || !scale4) return c ? fail(c, VKRHIP_ERR_ARG, "null TRS array") : VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_trs"));
+  TRY(bind_device(c));
+  TRY(dev_alloc(c, c->pos, c->cfg.max_nodes));
+  TRY(dev_alloc(c, c->quat, c->cfg.max_nodes));
+  TRY(dev_alloc(c, c->scale, c->cfg.max_nodes));
+  c->have_trs = true;
+  if (count == 0) return VKRHIP_OK;
+  HIP_TRY(c, hipMemcpyAsync(c->pos.p + first, pos4, count * 16, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->quat.p + first, quat4, count * 16, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->scale.p + first, scale4, count * 16, hipMemcpyHostToDevice, c->stream));
+  // transform setters set DIRTY_LOCAL (vkr_scene_system.h:70-72)
+  std::vector<uint8_t> f(count);
+  HIP_TRY(c, hipMemcpyAsync(f.data(), c->flags.p + first, count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto &x : f) x |= VKRHIP_DIRTY_LOCAL;
+  HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VKRHIP_OK;
+}
+
+int vkrhip_upload_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *local16) {
+  if (!c || !local16) return c ? fail(c, VKRHIP_ERR_ARG, "null locals") : VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_locals"));
+  if (count == 0) return VKRHIP_OK;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipMemcpyAsync(c->local.p + first * 4, local16, count * 64, hipMemcpyHostToDevice,
+                            c->stream));
+  std::vector<uint8_t> f(count);
+  HIP_TRY(c, hipMemcpyAsync(f.data(), c->flags.p + first, count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto &x : f) x |= VKRHIP_DIRTY_WORLD;
+  HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VKRHIP_OK;
+}
+
+int vkrhip_upload_worlds(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *world16) {
+  if (!c || !world16) return c ? fail(c, VKRHIP_ERR_ARG, "null worlds") : VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_worlds"));
+  if (count == 0) return VKRHIP_OK;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipMemcpyAsync(c->world.p + first * 4, world16, count * 64, hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VKRHIP_OK;
+}
+
+int vkrhip_upload_node_flags(vkrhip_ctx *c, uint64_t first, uint64_t count, const uint8_t *flags) {
+  if (!c || !flags) return c ? fail(c, VKRHIP_ERR_ARG, "null flags") : VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_node_flags"));
+  if (count == 0) return VKRHIP_OK;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, flags, count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VKRHIP_OK;
+}
+
+int vkrhip_mark_all(vkrhip_ctx *c, uint8_t flags) {
+  if (!c) return VKRHIP_ERR_ARG;
+  // folded into the next transform launch instead of a separate pass over flags[]
+  c->force_flags |= flags;
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// candidates
+// ---------------------------------------------------------------------------
+int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const uint32_t *ident,
+                          const uint32_t *matbits, const float *bounds) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if (n > c->cfg.max_candidates)
+    return fail(c, VKRHIP_ERR_CAPACITY, "n %llu exceeds max_candidates %llu", (unsigned long long)n,
+                (unsigned long long)c->cfg.max_candidates);
+  if (n && (!ident || !matbits || !bounds)) return fail(c, VKRHIP_ERR_ARG, "null candidate array");
+  if (!node && n > c->cfg.max_nodes)
+    return fail(c, VKRHIP_ERR_ARG, "identity node mapping needs n <= max_nodes");
+  if (node) {
+    for (uint64_t i = 0; i < n; ++i)
+      if (node[i] >= c->cfg.max_nodes)
+        return fail(c, VKRHIP_ERR_ARG, "node[%llu] = %u out of range", (unsigned long long)i, node[i]);
+  }
+  TRY(bind_device(c));
+  uint64_t blend = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t m = matbits[i];
+    if ((m & VKRHIP_MAT_ALPHA_MASK) == 2u && !(m & VKRHIP_MAT_TRANSMISSIVE)) blend++;
+  }
+  c->n_cand = n;
+  c->node_identity = node == nullptr;
+  c->blend_rows = blend;
+  if (n) {
+    if (node) {
+      TRY(dev_alloc(c, c->node, c->cfg.max_candidates));
+      HIP_TRY(c, hipMemcpyAsync(c->node.p, node, n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->ident.p, ident, n * 32, hipMemcpyHostToDevice, c->stream));
+    DevBuf<uint32_t> d_mat;
+    DevBuf<float4> d_bounds;
+    TRY(dev_alloc(c, d_mat, n));
+    int rc = dev_alloc(c, d_bounds, n * 3);
+    if (rc != VKRHIP_OK) {
+      dev_free(d_mat);
+      return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_mat.p, matbits, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(d_bounds.p, bounds, n * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_prepare_candidates, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                         c->stream, d_mat.p, d_bounds.p, c->sphere.p, c->cflags.p, n);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_mat);
+    dev_free(d_bounds);
+    if (e != hipSuccess)
+      return fail(c, VKRHIP_ERR_HIP, "candidate upload failed: %s", hipGetErrorString(e));
+  }
+  // transparent buffers sized by the rows that can ever enter the blend list
+  const uint64_t tcap = std::max<uint64_t>(1, std::min<uint64_t>(blend, c->cfg.transparent_capacity));
+  if (tcap > c->tcap || !c->tlist.p) {
+    TRY(dev_alloc(c, c->tlist, tcap));
+    TRY(dev_alloc(c, c->keys_a, tcap));
+    TRY(dev_alloc(c, c->keys_b, tcap));
+    TRY(dev_alloc(c, c->out_keys, tcap));
+    TRY(dev_alloc(c, c->vals_a, tcap));
+    TRY(dev_alloc(c, c->vals_b, tcap));
+    TRY(dev_alloc(c, c->out_source, tcap));
+    c->sort_tiles_stride = (uint32_t)ceil_div(tcap, SORT_TILE);
+    TRY(dev_alloc(c, c->hist, (size_t)SORT_RADIX * c->sort_tiles_stride));
+    TRY(dev_alloc(c, c->draws, tcap * 3));
+    TRY(dev_alloc(c, c->instances, tcap * 5));
+    c->tcap = tcap;
+  }
+  return VKRHIP_OK;
+}
+
+int vkrhip_set_views(vkrhip_ctx *c, uint32_t views, const float *planes,
+                     const uint32_t *required_flags, const float *camera_view) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if (views == 0 || views > c->cfg.max_views)
+    return fail(c, VKRHIP_ERR_CAPACITY, "views %u outside 1..max_views %u", views, c->cfg.max_views);
+  if (!planes || !required_flags || !camera_view) return fail(c, VKRHIP_ERR_ARG, "null view array");
+  TRY(bind_device(c));
+  std::vector<float> eps((size_t)views * 6, 0.f);
+  for (uint32_t k = 0; k < views * 6; ++k) {
+    const float d = std::fabs(planes[4 * k + 3]);
+    eps[k] = c->cfg.tie_epsilon * (d > 1.0f ? d : 1.0f);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->planes.p, planes, (size_t)views * 96, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->tie_eps.p, eps.data(), eps.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->required.p, required_flags, (size_t)views * 4, hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->camera_view.p, camera_view, 64, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->views = views;
+  return VKRHIP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// the frame
+// ---------------------------------------------------------------------------
+static int launch_transform(vkrhip_ctx *c) {
+  StageTimer timer(c, VKRHIP_TIMER_TRANSFORM);
+  const uint32_t levels = c->level_offsets.empty() ? 0u : (uint32_t)c->level_offsets.size() - 1u;
+  for (uint32_t l = 0; l < levels; ++l) {
+    TransformArgs a{};
+    a.parent = c->parent.p;
+    a.pos = c->have_trs ? c->pos.p : nullptr;
+    a.quat = c->quat.p;
+    a.scale = c->scale.p;
+    a.local = c->local.p;
+    a.world = c->world.p;
+    a.flags = c->flags.p;
+    a.nodes_updated = c->counters.p + CNT_NODES_UPDATED;
+    a.begin = c->level_offsets[l];
+    a.end = c->level_offsets[l + 1];
+    a.force = c->force_flags;
+    if (a.end == a.begin) continue;
+    const unsigned grid = (unsigned)ceil_div(a.end - a.begin, TF_TILE);
+    if (l == 0 || !c->parent.p)
+      hipLaunchKernelGGL(k_propagate_level<false>, dim3(grid), dim3(TF_BLOCK), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(k_propagate_level<true>, dim3(grid), dim3(TF_BLOCK), 0, c->stream, a);
+  }
+  c->force_flags = 0;
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+template <bool IDENTITY>
+static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned grid, bool ties,
+                                    bool bounds_out) {
+  if (ties) {
+    if (bounds_out)
+      hipLaunchKernelGGL((k_classify<IDENTITY, true, true>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_classify<IDENTITY, true, false>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+  } else {
+    if (bounds_out)
+      hipLaunchKernelGGL((k_classify<IDENTITY, false, true>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_classify<IDENTITY, false, false>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+  }
+}
+
+static int launch_cull(vkrhip_ctx *c, bool bounds_out) {
+  const uint64_t n = c->n_cand;
+  const uint64_t tiles = ceil_div(n, CULL_TILE);
+  if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
+  if (tiles) {
+    StageTimer timer(c, VKRHIP_TIMER_CLASSIFY);
+    CullArgs a{};
+    a.world = c->world.p;
+    a.node = c->node_identity ? nullptr : c->node.p;
+    a.sphere = c->sphere.p;
+    a.cflags = c->cflags.p;
+    a.planes = c->planes.p;
+    a.tie_eps = c->tie_eps.p;
+    a.required = c->required.p;
+    a.masks = c->masks.p;
+    a.tvis = c->tvis.p;
+    a.world_bounds = c->world_bounds.p;
+    a.tile_counts = c->tile_counts.p;
+    a.counters = c->counters.p;
+    a.ties = c->ties.p;
+    a.n = n;
+    a.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
+    a.tiles_stride = c->tiles_stride;
+    a.views = c->views;
+    const bool ties = c->cfg.tie_epsilon > 0.f;
+    if (c->node_identity)
+      launch_classify_variant<true>(c, a, (unsigned)tiles, ties, bounds_out);
+    else
+      launch_classify_variant<false>(c, a, (unsigned)tiles, ties, bounds_out);
+    HIP_TRY(c, hipGetLastError());
+  }
+  {
+    StageTimer timer(c, VKRHIP_TIMER_SCAN);
+    ScanArgs s{};
+    s.tile_counts = c->tile_counts.p;
+    s.states = c->states.p;
+    s.counters = c->counters.p;
+    s.tiles = tiles;
+    s.tiles_stride = c->tiles_stride;
+    s.views = c->views;
+    s.partition_capacity = c->cfg.partition_capacity;
+    s.visible_capacity = c->visible_stride;
+    s.transparent_capacity = c->tcap;
+    hipLaunchKernelGGL(k_scan, dim3(c->views + 1u), dim3(SCAN_BLOCK), 0, c->stream, s);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (tiles) {
+    StageTimer timer(c, VKRHIP_TIMER_SCATTER);
+    ScatterArgs s{};
+    s.masks = c->masks.p;
+    s.cflags = c->cflags.p;
+    s.tvis = c->tvis.p;
+    s.tile_offsets = c->tile_counts.p;
+    s.states = c->states.p;
+    s.visible = c->visible.p;
+    s.tlist = c->tlist.p;
+    s.n = n;
+    s.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
+    s.tiles_stride = c->tiles_stride;
+    s.visible_stride = c->visible_stride;
+    s.transparent_capacity = c->tcap;
+    s.index_base = c->cfg.source_index_base;
+    s.views = c->views;
+    s.partition_capacity = c->cfg.partition_capacity;
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)tiles), dim3(CULL_BLOCK), 0, c->stream, s);
+    HIP_TRY(c, hipGetLastError());
+  }
+  return VKRHIP_OK;
+}
+
+static int launch_transparent(vkrhip_ctx *c) {
+  const uint64_t cap = std::min<uint64_t>(c->tcap, std::max<uint64_t>(c->blend_rows, 1));
+  {
+    StageTimer timer(c, VKRHIP_TIMER_KEYGEN);
+    KeygenArgs k{};
+    k.tlist = c->tlist.p;
+    k.counters = c->counters.p;
+    k.world = c->world.p;
+    k.node = c->node_identity ? nullptr : c->node.p;
+    k.sphere = c->sphere.p;
+    k.view = c->camera_view.p;
+    k.keys = c->keys_a.p;
+    k.vals = c->vals_a.p;
+    k.index_base = c->cfg.source_index_base;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, 256), 2048);
+    hipLaunchKernelGGL(k_keygen, dim3(grid), dim3(256), 0, c->stream, k);
+    HIP_TRY(c, hipGetLastError());
+  }
+  bool in_a = true;
+  {
+    StageTimer timer(c, VKRHIP_TIMER_SORT);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
+    // depth bits only: the low word is already ordered by construction
+    for (uint32_t shift = 32; shift < 64; shift += 8) {
+      SortArgs s{};
+      s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
+      s.vals_in = in_a ? c->vals_a.p : c->vals_b.p;
+      s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
+      s.vals_out = in_a ? c->vals_b.p : c->vals_a.p;
+      s.hist = c->hist.p;
+      s.counters = c->counters.p;
+      s.tiles_stride = c->sort_tiles_stride;
+      s.shift = shift;
+      hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
+      hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+      in_a = !in_a;
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
+  c->sorted_in_a = in_a;
+  {
+    StageTimer timer(c, VKRHIP_TIMER_EMIT);
+    EmitArgs e{};
+    e.keys = in_a ? c->keys_a.p : c->keys_b.p;
+    e.vals = in_a ? c->vals_a.p : c->vals_b.p;
+    e.counters = c->counters.p;
+    e.world = c->world.p;
+    e.node = c->node_identity ? nullptr : c->node.p;
+    e.ident = c->ident.p;
+    e.draws = c->draws.p;
+    e.instances = c->instances.p;
+    e.out_keys = c->out_keys.p;
+    e.out_source = c->out_source.p;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, 32), 4096);
+    hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, e);
+    HIP_TRY(c, hipGetLastError());
+  }
+  return VKRHIP_OK;
+}
+
+static int launch_candidates(vkrhip_ctx *c) {
+  TRY(dev_alloc(c, c->cand_rows, std::max<uint64_t>(c->cfg.max_candidates, 1) * 9));
+  if (!c->n_cand) return VKRHIP_OK;
+  StageTimer timer(c, VKRHIP_TIMER_CANDIDATES);
+  CandidateEmitArgs a{};
+  a.world = c->world.p;
+  a.node = c->node_identity ? nullptr : c->node.p;
+  a.ident = c->ident.p;
+  a.sphere = c->sphere.p;
+  a.cflags = c->cflags.p;
+  a.rows = c->cand_rows.p;
+  a.n = c->n_cand;
+  hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand, 16)), dim3(256), 0,
+                     c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+extern "C" {
+
+int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if ((stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_TRANSPARENT)) && c->views == 0)
+    return fail(c, VKRHIP_ERR_STATE, "vkrhip_set_views has not been called");
+  if ((stages & VKRHIP_STAGE_TRANSPARENT) && !(stages & VKRHIP_STAGE_CULL))
+    return fail(c, VKRHIP_ERR_STATE, "STAGE_TRANSPARENT needs STAGE_CULL in the same frame");
+  if ((stages & VKRHIP_STAGE_WORLD_BOUNDS) && !(stages & VKRHIP_STAGE_CULL))
+    return fail(c, VKRHIP_ERR_STATE, "STAGE_WORLD_BOUNDS needs STAGE_CULL in the same frame");
+  if ((stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_CANDIDATES)) && c->node_identity &&
+      c->n_cand > c->cfg.max_nodes)
+    return fail(c, VKRHIP_ERR_STATE, "identity node mapping with more candidates than nodes");
+  TRY(bind_device(c));
+  {
+    StageTimer frame_timer(c, VKRHIP_TIMER_FRAME);
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * CNT_COUNT, c->stream));
+    if (c->cfg.tie_epsilon > 0.f)
+      HIP_TRY(c, hipMemsetAsync(c->ties.p, 0, sizeof(unsigned long long) * VKRHIP_MAX_VIEWS, c->stream));
+    if (stages & VKRHIP_STAGE_TRANSFORM) TRY(launch_transform(c));
+    if (stages & VKRHIP_STAGE_CULL) TRY(launch_cull(c, (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0));
+    if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c));
+    if (stages & VKRHIP_STAGE_CANDIDATES) TRY(launch_candidates(c));
+  }
+  c->frame_ran = true;
+  c->last_stages = stages;
+  return VKRHIP_OK;
+}
+
+int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  if (!c->frame_ran) return fail(c, VKRHIP_ERR_STATE, "no frame has run");
+  TRY(bind_device(c));
+  uint32_t cnt[CNT_COUNT];
+  std::memset(out, 0, sizeof(*out));
+  HIP_TRY(c, hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out->views, c->states.p, sizeof(CompactionState) * VKRHIP_MAX_VIEWS,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out->near_plane_ties, c->ties.p, sizeof(uint64_t) * VKRHIP_MAX_VIEWS,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const bool culled = (c->last_stages & VKRHIP_STAGE_CULL) != 0;
+  out->stats.objects_tested = culled ? (uint32_t)c->n_cand : 0u;
+  out->stats.objects_culled_camera = cnt[CNT_CULLED_CAMERA];
+  out->stats.objects_without_bounds = cnt[CNT_WITHOUT_BOUNDS];
+  out->gpu_candidate_count = (uint32_t)c->n_cand;
+  out->gpu_camera_opaque_candidate_count = cnt[CNT_CAMERA_OPAQUE];
+  out->transmission_gpu_candidate_count = cnt[CNT_TRANSMISSION];
+  out->transparent_draw_count = cnt[CNT_TRANSPARENT];
+  out->transparent_overflow = cnt[CNT_TRANSPARENT_TOTAL] - cnt[CNT_TRANSPARENT];
+  out->nodes_updated = cnt[CNT_NODES_UPDATED];
+  out->view_count = c->views;
+  for (uint32_t v = c->views; v < VKRHIP_MAX_VIEWS; ++v) {
+    std::memset(&out->views[v], 0, sizeof(out->views[v]));
+    out->near_plane_ties[v] = 0;
+  }
+  return VKRHIP_OK;
+}
+
+int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->world = reinterpret_cast<const float *>(c->world.p);
+  out->node_flags = c->flags.p;
+  out->visible = c->visible.p;
+  out->visible_stride = c->visible_stride;
+  out->transparent_visible = c->tvis.p;
+  out->transparent_draws = c->draws.p;
+  out->transparent_instances = c->instances.p;
+  out->transparent_keys = c->out_keys.p;
+  out->transparent_source = c->out_source.p;
+  out->gpu_candidates = c->cand_rows.p;
+  out->world_bounds = reinterpret_cast<const float *>(c->world_bounds.p);
+  out->device_counts = c->counters.p;
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// read-back helpers
+// ---------------------------------------------------------------------------
+static int read_back(vkrhip_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (bytes == 0) return VKRHIP_OK;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VKRHIP_OK;
+}
+
+int vkrhip_read_world(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out16) {
+  if (!c || !out16) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "read_world"));
+  return read_back(c, out16, c->world.p + first * 4, count * 64);
+}
+
+int vkrhip_read_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out16) {
+  if (!c || !out16) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "read_locals"));
+  return read_back(c, out16, c->local.p + first * 4, count * 64);
+}
+
+int vkrhip_read_node_flags(vkrhip_ctx *c, uint64_t first, uint64_t count, uint8_t *out) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "read_node_flags"));
+  return read_back(c, out, c->flags.p + first, count);
+}
+
+int vkrhip_read_visible(vkrhip_ctx *c, uint32_t view, uint64_t count, uint32_t *out) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  if (view >= c->cfg.max_views) return fail(c, VKRHIP_ERR_ARG, "view %u out of range", view);
+  TRY(check_range(c, 0, count, c->visible_stride, "read_visible"));
+  return read_back(c, out, c->visible.p + (uint64_t)view * c->visible_stride, count * 4);
+}
+
+int vkrhip_read_transparent_visible(vkrhip_ctx *c, uint64_t first, uint64_t count, uint8_t *out) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_transparent_visible"));
+  return read_back(c, out, c->tvis.p + first, count);
+}
+
+int vkrhip_read_transparent(vkrhip_ctx *c, uint64_t count, void *draws48, void *instances80,
+                            uint64_t *keys, uint32_t *source) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, 0, count, c->tcap, "read_transparent"));
+  if (draws48) TRY(read_back(c, draws48, c->draws.p, count * 48));
+  if (instances80) TRY(read_back(c, instances80, c->instances.p, count * 80));
+  if (keys) TRY(read_back(c, keys, c->out_keys.p, count * 8));
+  if (source) TRY(read_back(c, source, c->out_source.p, count * 4));
+  return VKRHIP_OK;
+}
+
+int vkrhip_read_candidates(vkrhip_ctx *c, uint64_t first, uint64_t count, void *rows144) {
+  if (!c || !rows144) return VKRHIP_ERR_ARG;
+  if (!c->cand_rows.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_CANDIDATES has not run");
+  TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_candidates"));
+  return read_back(c, rows144, c->cand_rows.p + first * 9, count * 144);
+}
+
+int vkrhip_read_world_bounds(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out4) {
+  if (!c || !out4) return VKRHIP_ERR_ARG;
+  if (!c->world_bounds.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_WORLD_BOUNDS has not run");
+  TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_world_bounds"));
+  return read_back(c, out4, c->world_bounds.p + first, count * 16);
+}
+
+int vkrhip_read_candidate_prep(vkrhip_ctx *c, uint64_t first, uint64_t count, float *sphere4,
+                               uint32_t *flags_bucket) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_candidate_prep"));
+  if (sphere4) TRY(read_back(c, sphere4, c->sphere.p + first, count * 16));
+  if (flags_bucket) TRY(read_back(c, flags_bucket, c->cflags.p + first, count * 4));
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------
+int vkrhip_set_profiling(vkrhip_ctx *c, int enabled) {
+  if (!c) return VKRHIP_ERR_ARG;
+  c->profiling = enabled != 0;
+  return VKRHIP_OK;
+}
+
+int vkrhip_get_timers(vkrhip_ctx *c, double *ms_out, uint64_t *samples_out, int reset) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  TRY(drain_timers(c));
+  for (int i = 0; i < VKRHIP_TIMER_COUNT; ++i) {
+    if (ms_out) ms_out[i] = c->timer_ms[i];
+    if (samples_out) samples_out[i] = c->timer_n[i];
+    if (reset) {
+      c->timer_ms[i] = 0.0;
+      c->timer_n[i] = 0;
+    }
+  }
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU draw-key merge
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+namespace vkr {
+
+// Rank-based G-way merge of descending runs with unique keys: the output slot of
+// an element is its index in its own run plus, for every other run, the number
+// of keys greater than it (found by binary search).
+__global__ __launch_bounds__(256) void k_merge_runs(const uint64_t *const *runs,
+                                                    const uint64_t *lengths, uint32_t g,
+                                                    uint64_t total, uint64_t *out) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  uint32_t q = 0;
+  uint64_t j = gid;
+  while (q < g && j >= lengths[q]) {
+    j -= lengths[q];
+    ++q;
+  }
+  const uint64_t key = runs[q][j];
+  uint64_t pos = j;
+  for (uint32_t r = 0; r < g; ++r) {
+    if (r == q) continue;
+    const uint64_t *run = runs[r];
+    uint64_t lo = 0, hi = lengths[r];
+    while (lo < hi) {  // first index whose key is <= `key` in a descending run
+      const uint64_t mid = (lo + hi) >> 1;
+      if (run[mid] > key)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    pos += lo;
+  }
+  out[pos] = key;
+}
+
+}  // namespace vkr
+
+extern "C" {
+
+int vkrhip_merge_runs(vkrhip_ctx *c, uint32_t g, const uint64_t *const *runs_keys,
+                      const uint64_t *lengths, uint64_t *out_keys_dev) {
+  if (!c || !runs_keys || !lengths || !out_keys_dev) return VKRHIP_ERR_ARG;
+  if (g == 0 || g > 64) return fail(c, VKRHIP_ERR_ARG, "run count %u outside 1..64", g);
+  TRY(bind_device(c));
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < g; ++r) total += lengths[r];
+  if (total == 0) return VKRHIP_OK;
+  TRY(dev_alloc(c, c->merge_ptrs, 64));
+  TRY(dev_alloc(c, c->merge_lens, 64));
+  HIP_TRY(c, hipMemcpyAsync(c->merge_ptrs.p, runs_keys, g * sizeof(void *), hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->merge_lens.p, lengths, g * sizeof(uint64_t), hipMemcpyHostToDevice,
+                            c->stream));
+  // the two small arrays above come from pageable host memory: make sure the
+  // copies have been staged before the caller's arrays go out of scope
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, c->stream,
+                     c->merge_ptrs.p, c->merge_lens.p, g, total, out_keys_dev);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+"""Host-side front end of the gfx950 scene-processing library.
+
+Mirrors the reference interfaces of the path it stands behind:
+
+* ``HipScene.set_hierarchy / upload_trs / upload_locals`` - the SceneTransform
+  columns that ``vkr_scene_update`` walks
+  (lib/src/renderer/systems/vkr_scene_system.c:1254-1337);
+* ``HipScene.set_candidates`` - the (instance, submesh) rows that
+  ``application_build_world_payload`` enumerates (lib/src/application.h:730-806);
+* ``HipScene.set_views`` - camera + cascades as the backend builds them
+  (lib/src/renderer/vulkan/vkr_vulkan_deferred.c:242-295);
+* ``HipScene.frame`` - one pass of transform -> cull -> sort on the device.
+
+Every call goes through the C ABI in include/vkr_hip_scene.h; there is no CPU
+fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+# numpy views of the reference's row layouts
+DRAW_DT = np.dtype({
+    "names": ["mesh", "geometry", "submesh_index", "material", "instance_count",
+              "first_instance", "sort_key"],
+    "formats": ["2<u4", "2<u4", "<u4", "2<u4", "<u4", "<u4", "<u8"],
+    "offsets": [0, 8, 16, 20, 28, 32, 40], "itemsize": 48})       # VkrDrawItem
+INSTANCE_DT = np.dtype({
+    "names": ["model", "object_id", "reserved"], "formats": ["16<f4", "<u4", "3<u4"],
+    "offsets": [0, 64, 68], "itemsize": 80})                      # VkrInstanceDataGPU
+CANDIDATE_DT = np.dtype({
+    "names": ["mesh", "geometry", "submesh_index", "material", "model", "object_id",
+              "reserved", "sphere", "state_bucket", "flags"],
+    "formats": ["2<u4", "2<u4", "<u4", "2<u4", "16<f4", "<u4", "3<u4", "4<f4", "<u4", "<u4"],
+    "offsets": [0, 8, 16, 20, 32, 96, 100, 112, 128, 132], "itemsize": 144})  # VkrWorldDrawCandidate
+
+
+@dataclass
+class ViewState:
+    """VkrGpuDrawCompactionState of one view (lib/src/renderer/vkr_gpu_abi.h:95-103)."""
+    execution_ranges: np.ndarray  # (4, 2) {offset, count}
+    bucket_counts: np.ndarray
+    bucket_cursors: np.ndarray
+    visible_count: int
+    overflow_count: int
+    near_plane_ties: int
+
+
+@dataclass
+class FrameResult:
+    objects_tested: int
+    objects_culled_camera: int
+    objects_without_bounds: int
+    gpu_candidate_count: int
+    gpu_camera_opaque_candidate_count: int
+    transmission_gpu_candidate_count: int
+    transparent_draw_count: int
+    transparent_overflow: int
+    nodes_updated: int
+    views: list
+
+
+def _check(lib, ctx, rc: int) -> None:
+    if rc != N.OK:
+        msg = lib.vkrhip_last_error(ctx)
+        raise N.VkrHipError(rc, msg.decode() if msg else "")
+
+
+class HipScene:
+    """One GPU's HBM-resident scene and its per-frame processing path."""
+
+    def __init__(self, max_nodes: int, max_candidates: int, max_views: int = 1, device: int = 0,
+                 partition_capacity: int = 0, visible_capacity: int = 0,
+                 transparent_capacity: int = 0, source_index_base: int = 0,
+                 tie_epsilon: float = 0.0):
+        self.lib = N.load()
+        cfg = N.Config()
+        cfg.struct_size = C.sizeof(N.Config)
+        cfg.device = device
+        cfg.max_nodes = max_nodes
+        cfg.max_candidates = max_candidates
+        cfg.max_views = max_views
+        cfg.partition_capacity = partition_capacity
+        cfg.visible_capacity = visible_capacity
+        cfg.transparent_capacity = transparent_capacity
+        cfg.source_index_base = source_index_base
+        cfg.tie_epsilon = tie_epsilon
+        cfg.flags = 0
+        self.ctx = C.c_void_p()
+        rc = self.lib.vkrhip_create(C.byref(cfg), C.byref(self.ctx))
+        if rc != N.OK:
+            msg = self.lib.vkrhip_last_error(None)
+            raise N.VkrHipError(rc, msg.decode() if msg else "")
+        self.max_nodes = max_nodes
+        self.max_candidates = max_candidates
+        self.max_views = max_views
+        self.n_nodes = 0
+        self.n_candidates = 0
+        self.views = 0
+        self.visible_capacity = visible_capacity or max_candidates
+
+    # ---- lifetime -------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "ctx", None) is not None and self.ctx:
+            self.lib.vkrhip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ok(self, rc: int) -> None:
+        _check(self.lib, self.ctx, rc)
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        self._ok(self.lib.vkrhip_set_stream(self.ctx, hip_stream))
+
+    def sync(self) -> None:
+        self._ok(self.lib.vkrhip_sync(self.ctx))
+
+    # ---- scene state ----------------------------------------------------
+    def set_hierarchy(self, parent, level_offsets) -> None:
+        level_offsets = np.ascontiguousarray(level_offsets, dtype=np.uint64)
+        levels = level_offsets.shape[0] - 1
+        n = int(level_offsets[-1]) if levels >= 0 and level_offsets.shape[0] else 0
+        p = None if parent is None else N.as_u32(parent)
+        self._ok(self.lib.vkrhip_set_hierarchy(self.ctx, N.ptr(p), n, N.ptr(level_offsets),
+                                               max(levels, 0)))
+        self.n_nodes = n
+
+    def upload_trs(self, pos4, quat4, scale4, first: int = 0) -> None:
+        pos4, quat4, scale4 = (N.as_f32(a).reshape(-1, 4) for a in (pos4, quat4, scale4))
+        self._ok(self.lib.vkrhip_upload_trs(self.ctx, first, pos4.shape[0], N.ptr(pos4),
+                                            N.ptr(quat4), N.ptr(scale4)))
+
+    def upload_locals(self, local16, first: int = 0) -> None:
+        local16 = N.as_f32(local16).reshape(-1, 16)
+        self._ok(self.lib.vkrhip_upload_locals(self.ctx, first, local16.shape[0], N.ptr(local16)))
+
+    def upload_worlds(self, world16, first: int = 0) -> None:
+        world16 = N.as_f32(world16).reshape(-1, 16)
+        self._ok(self.lib.vkrhip_upload_worlds(self.ctx, first, world16.shape[0], N.ptr(world16)))
+
+    def upload_node_flags(self, flags, first: int = 0) -> None:
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._ok(self.lib.vkrhip_upload_node_flags(self.ctx, first, flags.shape[0], N.ptr(flags)))
+
+    def mark_all(self, flags: int = N.DIRTY_WORLD) -> None:
+        self._ok(self.lib.vkrhip_mark_all(self.ctx, flags))
+
+    # ---- candidates / views --------------------------------------------
+    def set_candidates(self, node, ident, matbits, bounds) -> None:
+        ident = N.as_u32(ident).reshape(-1, 8)
+        n = ident.shape[0]
+        matbits = N.as_u32(matbits)
+        bounds = N.as_f32(bounds).reshape(-1, 12)
+        if matbits.shape[0] != n or bounds.shape[0] != n:
+            raise ValueError("candidate arrays disagree on the row count")
+        nd = None if node is None else N.as_u32(node)
+        if nd is not None and nd.shape[0] != n:
+            raise ValueError("node array disagrees on the row count")
+        self._ok(self.lib.vkrhip_set_candidates(self.ctx, n, N.ptr(nd), N.ptr(ident),
+                                                N.ptr(matbits), N.ptr(bounds)))
+        self.n_candidates = n
+
+    def set_views(self, planes, required_flags, camera_view) -> None:
+        planes = N.as_f32(planes).reshape(-1, 24)
+        required = N.as_u32(required_flags)
+        view = N.as_f32(camera_view).reshape(16)
+        if required.shape[0] != planes.shape[0]:
+            raise ValueError("planes and required_flags disagree on the view count")
+        self._ok(self.lib.vkrhip_set_views(self.ctx, planes.shape[0], N.ptr(planes), N.ptr(required),
+                                           N.ptr(view)))
+        self.views = planes.shape[0]
+
+    # ---- the frame ------------------------------------------------------
+    def frame(self, stages: int = N.STAGE_ALL) -> None:
+        self._ok(self.lib.vkrhip_frame(self.ctx, stages))
+
+    def frame_info(self) -> FrameResult:
+        info = N.FrameInfo()
+        self._ok(self.lib.vkrhip_get_frame_info(self.ctx, C.byref(info)))
+        views = []
+        for v in range(info.view_count):
+            st = info.views[v]
+            views.append(ViewState(
+                execution_ranges=np.array([[st.execution_ranges[b][0], st.execution_ranges[b][1]]
+                                           for b in range(4)], np.uint32),
+                bucket_counts=np.array(list(st.bucket_counts), np.uint32),
+                bucket_cursors=np.array(list(st.bucket_cursors), np.uint32),
+                visible_count=int(st.visible_count), overflow_count=int(st.overflow_count),
+                near_plane_ties=int(info.near_plane_ties[v])))
+        return FrameResult(
+            objects_tested=info.stats.objects_tested,
+            objects_culled_camera=info.stats.objects_culled_camera,
+            objects_without_bounds=info.stats.objects_without_bounds,
+            gpu_candidate_count=info.gpu_candidate_count,
+            gpu_camera_opaque_candidate_count=info.gpu_camera_opaque_candidate_count,
+            transmission_gpu_candidate_count=info.transmission_gpu_candidate_count,
+            transparent_draw_count=info.transparent_draw_count,
+            transparent_overflow=info.transparent_overflow,
+            nodes_updated=info.nodes_updated, views=views)
+
+    def device_outputs(self) -> N.DeviceOutputs:
+        out = N.DeviceOutputs()
+        self._ok(self.lib.vkrhip_get_device_outputs(self.ctx, C.byref(out)))
+        return out
+
+    # ---- read-back ------------------------------------------------------
+    def read_world(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.n_nodes - first if count is None else count
+        out = np.empty((count, 16), np.float32)
+        self._ok(self.lib.vkrhip_read_world(self.ctx, first, count, N.ptr(out)))
+        return out
+
+    def read_locals(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.n_nodes - first if count is None else count
+        out = np.empty((count, 16), np.float32)
+        self._ok(self.lib.vkrhip_read_locals(self.ctx, first, count, N.ptr(out)))
+        return out
+
+    def read_node_flags(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.n_nodes - first if count is None else count
+        out = np.empty(count, np.uint8)
+        self._ok(self.lib.vkrhip_read_node_flags(self.ctx, first, count, N.ptr(out)))
+        return out
+
+    def read_visible(self, view: int, count: int) -> np.ndarray:
+        out = np.empty(count, np.uint32)
+        self._ok(self.lib.vkrhip_read_visible(self.ctx, view, count, N.ptr(out)))
+        return out
+
+    def read_transparent_visible(self) -> np.ndarray:
+        out = np.empty(self.n_candidates, np.uint8)
+        self._ok(self.lib.vkrhip_read_transparent_visible(self.ctx, 0, self.n_candidates, N.ptr(out)))
+        return out
+
+    def read_transparent(self, count: int):
+        draws = np.zeros(count, DRAW_DT)
+        inst = np.zeros(count, INSTANCE_DT)
+        keys = np.zeros(count, np.uint64)
+        src = np.zeros(count, np.uint32)
+        self._ok(self.lib.vkrhip_read_transparent(self.ctx, count, N.ptr(draws), N.ptr(inst),
+                                                  N.ptr(keys), N.ptr(src)))
+        return draws, inst, keys, src
+
+    def read_candidates(self) -> np.ndarray:
+        out = np.zeros(self.n_candidates, CANDIDATE_DT)
+        self._ok(self.lib.vkrhip_read_candidates(self.ctx, 0, self.n_candidates, N.ptr(out)))
+        return out
+
+    def read_world_bounds(self) -> np.ndarray:
+        out = np.empty((self.n_candidates, 4), np.float32)
+        self._ok(self.lib.vkrhip_read_world_bounds(self.ctx, 0, self.n_candidates, N.ptr(out)))
+        return out
+
+    def read_candidate_prep(self):
+        sphere = np.empty((self.n_candidates, 4), np.float32)
+        flags = np.empty(self.n_candidates, np.uint32)
+        self._ok(self.lib.vkrhip_read_candidate_prep(self.ctx, 0, self.n_candidates, N.ptr(sphere),
+                                                     N.ptr(flags)))
+        return sphere, flags
+
+    # ---- timing ---------------------------------------------------------
+    def set_profiling(self, enabled: bool) -> None:
+        self._ok(self.lib.vkrhip_set_profiling(self.ctx, int(enabled)))
+
+    def timers(self, reset: bool = False) -> dict:
+        ms = np.zeros(len(N.TIMER_NAMES), np.float64)
+        n = np.zeros(len(N.TIMER_NAMES), np.uint64)
+        self._ok(self.lib.vkrhip_get_timers(self.ctx, N.ptr(ms), N.ptr(n), int(reset)))
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(N.TIMER_NAMES)}
+
+    def merge_runs(self, run_ptrs, lengths, out_ptr: int) -> None:
+        g = len(run_ptrs)
+        ptrs = (C.c_void_p * g)(*run_ptrs)
+        lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+        self._ok(self.lib.vkrhip_merge_runs(self.ctx, g, C.cast(ptrs, C.c_void_p), N.ptr(lens),
+                                            out_ptr))
+
+
+# ---- host-side leaf mirrors ---------------------------------------------
+def frustum_from_matrix(view_projection) -> np.ndarray:
+    """vkr_frustum_from_matrix (lib/src/math/vkr_frustum.c:44-66)."""
+    lib = N.load()
+    vp = N.as_f32(view_projection).reshape(16)
+    out = np.empty(24, np.float32)
+    lib.vkrhip_frustum_from_matrix(N.ptr(vp), N.ptr(out))
+    return out
+
+
+def frustum_from_view_projection(view, projection) -> np.ndarray:
+    """vkr_frustum_from_view_projection (lib/src/math/vkr_frustum.c:33-38)."""
+    lib = N.load()
+    v = N.as_f32(view).reshape(16)
+    p = N.as_f32(projection).reshape(16)
+    out = np.empty(24, np.float32)
+    lib.vkrhip_frustum_from_view_projection(N.ptr(v), N.ptr(p), N.ptr(out))
+    return out
+
+
+def mat4_mul(a, b) -> np.ndarray:
+    """mat4_mul (lib/src/math/mat.h:1145-1163)."""
+    lib = N.load()
+    a = N.as_f32(a).reshape(16)
+    b = N.as_f32(b).reshape(16)
+    out = np.empty(16, np.float32)
+    lib.vkrhip_mat4_mul(N.ptr(a), N.ptr(b), N.ptr(out))
+    return out
+
+
+def build_view_set(view, projection, light_view_proj=None):
+    """Camera + cascade plane sets and required flags
+    (lib/src/renderer/vulkan/vkr_vulkan_deferred.c:257-273,292-294)."""
+    lib = N.load()
+    v = N.as_f32(view).reshape(16)
+    p = N.as_f32(projection).reshape(16)
+    lvp = np.zeros((0, 16), np.float32) if light_view_proj is None else \
+        N.as_f32(light_view_proj).reshape(-1, 16)
+    cascades = lvp.shape[0]
+    planes = np.empty((1 + cascades, 24), np.float32)
+    required = np.empty(1 + cascades, np.uint32)
+    lib.vkrhip_build_view_set(N.ptr(v), N.ptr(p), N.ptr(lvp) if cascades else None, cascades,
+                              N.ptr(planes), N.ptr(required))
+    return planes, required
+
+
+def levelize(parent):
+    """BFS relabelling of an arbitrary parent array
+    (scene_rebuild_topo_order, lib/src/renderer/systems/vkr_scene_system.c:777-843).
+    Returns (order, new_parent, level_offsets)."""
+    lib = N.load()
+    parent = N.as_u32(parent)
+    n = parent.shape[0]
+    order = np.empty(n, np.uint32)
+    new_parent = np.empty(n, np.uint32)
+    offsets = np.zeros(n + 2, np.uint64)
+    levels = lib.vkrhip_levelize(N.ptr(parent), n, N.ptr(order), N.ptr(new_parent), N.ptr(offsets))
+    if n and not levels:
+        raise MemoryError("vkrhip_levelize failed")
+    return order, new_parent, offsets[: levels + 1].copy()
