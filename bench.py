@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-frame scene-processing path on MI355X.
+
+One "step" = one frame: every node moved (DIRTY_WORLD) -> world-transform
+propagation -> multi-view sphere cull + ordered compaction -> transparent key
+generation, radix sort and draw emission, over a synthetic instance hierarchy
+already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+Workloads (BASELINE.json configs): flat1m (config 2, default), deep16m
+(config 3), flat32m (config 4's per-GPU shard), probes64 (config 5 shape).
+With N > 1 every rank owns a contiguous shard of the same size (weak scaling)
+and the per-frame exchange all-gathers the visible lists and merges the sorted
+draw-key runs.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (instances per GPU, hierarchy depth, cascades, extra probe views)
+    "flat1m": dict(n=1 << 20, depth=1, cascades=0, probes=0,
+                   desc="1M synthetic instances, flat hierarchy, 1 view"),
+    "deep16m": dict(n=1 << 24, depth=8, cascades=4, probes=0,
+                    desc="16M instances, depth-8 hierarchy, main view + 4 shadow cascades"),
+    "flat32m": dict(n=1 << 25, depth=1, cascades=0, probes=0,
+                    desc="32M instances per GPU (256M over 8), flat hierarchy, 1 view"),
+    "probes64": dict(n=1 << 24, depth=1, cascades=0, probes=63,
+                     desc="16M instances per GPU, flat hierarchy, 64 views"),
+}
+
+# Algorithmic HBM bytes per unit for each kernel of the frame:
+#   transform: local 64 + parent index 4 (non-root) + flags 1+1 + world 64
+#   classify : world 64 + sphere 16 + flags 4 in; view-mask words 4*W + visible byte 1 out
+def kernel_bytes(name: str, n: int, depth: int, views: int) -> float:
+    words = (views + 31) // 32
+    if name == "transform":
+        return n * (64 + 64 + 2 + (4 if depth > 1 else 0))
+    if name == "classify":
+        return n * (64 + 16 + 4 + 4 * words + 1)
+    raise KeyError(name)
+
+
+def build_scene(workload: dict, rank: int, seed: int):
+    from vulkan_renderer_amd import synth
+    n = workload["n"]
+    if workload["depth"] > 1:
+        sc = synth.deep_scene(n, depth=workload["depth"], seed=seed + 1 + rank)
+    else:
+        sc = synth.flat_scene(n, seed=seed, first=rank * n)
+    vs = synth.camera_views(cascades=workload["cascades"])
+    extra = None
+    if workload["probes"]:
+        extra, _ = synth.ring_views(workload["probes"])
+    return sc, vs, extra
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="flat1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--instances", type=int, default=0, help="override instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  "torch.distributed.run --nproc-per-node N", file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from vulkan_renderer_amd import HipScene, build_view_set, frustum_from_matrix
+    from vulkan_renderer_amd import _native as N
+    from vulkan_renderer_amd.parallel import ShardExchange
+
+    workload = dict(WORKLOADS[args.workload])
+    if args.instances:
+        workload["n"] = args.instances
+    n = workload["n"]
+    sc, vs, extra = build_scene(workload, rank, args.seed)
+    planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
+    if extra is not None:
+        planes = np.concatenate([planes, np.stack([frustum_from_matrix(m) for m in extra])])
+        required = np.concatenate([required, np.full(len(extra), N.CAND_SHADOW_CASTER, np.uint32)])
+    views = planes.shape[0]
+
+    hs = HipScene(max_nodes=sc.n, max_candidates=sc.n, max_views=views, device=local_rank,
+                  source_index_base=rank * n)
+    stream = torch.cuda.current_stream()
+    hs.set_stream(stream.cuda_stream)
+    hs.set_hierarchy(sc.parent if workload["depth"] > 1 else None, sc.level_offsets)
+    hs.upload_trs(sc.pos, sc.quat, sc.scale)
+    hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+    hs.set_views(planes, required, vs.view)
+    hs.frame(N.STAGE_TRANSFORM)  # materialise local matrices from TRS once (not timed)
+    hs.sync()
+    exchange = ShardExchange(hs, world, rank, views) if world > 1 else None
+
+    def step():
+        hs.mark_all(N.DIRTY_WORLD)   # every node moved this frame
+        hs.frame(N.STAGE_ALL)
+        if exchange is not None:
+            exchange.run()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up, also used to find the dominant kernel
+    hs.set_profiling(True)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    warm = hs.timers(reset=True)
+    dominant = max(("transform", "classify"), key=lambda k: warm[k][0])
+    hs.set_profiling([dominant])
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timers = hs.timers(reset=True)
+    info = hs.frame_info()
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    total_instances = n * world
+    value = total_instances * args.steps / elapsed
+
+    dom_ms, dom_n = timers[dominant]
+    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    if dominant == "transform":
+        launches = len(sc.level_offsets) - 1
+    else:
+        launches = 1
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], views)
+    achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": "k_propagate_level" if dominant == "transform" else "k_classify",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "avg_launch_us": round(dom_avg_s * 1e6 / launches, 2),
+        "launches_per_step": launches,
+        "algorithmic_bytes_per_step": int(alg_bytes),
+    }
+    stage_us = {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in warm.items() if v[1]}
+
+    result = {
+        "metric": "instances/sec (transform+cull+sort)",
+        "value": value, "unit": "instances/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {workload['desc']}",
+            "instances_per_gpu": n, "instances_total": total_instances, "views": views,
+            "hierarchy_depth": len(sc.level_offsets) - 1,
+            "visible_camera": info.views[0].visible_count,
+            "transparent_draws": info.transparent_draw_count,
+            "exchange": "allgather visible lists + draw-key merge" if world > 1 else "none",
+        },
+        "roofline": roofline,
+        "stage_us_warmup": stage_us,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sc, planes, required, vs, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result))
+    hs.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(sc, planes, required, vs, budget_s: float) -> dict:
+    """The CPU oracle (a port of the reference's loop structure) timed on the
+    host, single thread like the reference's render thread, on a bounded prefix
+    of the same workload."""
+    from oracle import pyoracle
+    pyoracle.build()
+    o = pyoracle.Oracle()
+    n = sc.n
+    flat = len(sc.level_offsets) == 2
+    # bounded sample: a prefix of the instance range (flat) keeps the workload's
+    # distribution; hierarchies are timed whole because subtrees interleave
+    sample = min(n, 1 << 20) if flat else n
+    local, _, _, _ = o.scene_update(sc.parent[:sample] if flat else sc.parent,
+                                    pos=sc.pos[:sample], quat=sc.quat[:sample],
+                                    scale=sc.scale[:sample],
+                                    flags=np.full(sample, 0x01, np.uint8))
+    h = o.baseline_create(sc.parent[:sample], local, None, sc.ident[:sample], sc.matbits[:sample],
+                          sc.bounds[:sample], planes, required, vs.view, vs.projection)
+    o.baseline_frame(h)  # warm
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        o.baseline_frame(h)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or frames >= 50:
+            break
+    o.baseline_destroy(h)
+    return {"value": sample * frames / dt, "unit": "instances/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} frames of the first {sample} instances of the workload, "
+                      f"all {planes.shape[0]} views, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    sys.exit(main())

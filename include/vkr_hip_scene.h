@@ -217,7 +217,8 @@ int vkrhip_read_candidate_prep(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
 #define VKRHIP_TIMER_CANDIDATES 7
 #define VKRHIP_TIMER_FRAME 8
 #define VKRHIP_TIMER_COUNT 9
-int vkrhip_set_profiling(vkrhip_ctx *ctx, int enabled);
+/* timer_mask: bit VKRHIP_TIMER_x set = bracket that stage with HIP events; 0 = off. */
+int vkrhip_set_profiling(vkrhip_ctx *ctx, uint32_t timer_mask);
 /* Accumulated milliseconds and sample counts since the last reset; waits for
  * outstanding work. */
 int vkrhip_get_timers(vkrhip_ctx *ctx, double *ms_out, uint64_t *samples_out, int reset);
@@ -228,6 +229,13 @@ int vkrhip_get_timers(vkrhip_ctx *ctx, double *ms_out, uint64_t *samples_out, in
  * host. Writes the merged descending keys and (rank,source) pairs. */
 int vkrhip_merge_runs(vkrhip_ctx *ctx, uint32_t g, const uint64_t *const *runs_keys,
                       const uint64_t *lengths, uint64_t *out_keys_dev);
+
+/* Segmented device copy of 32-bit elements: descriptor d = {src offset, dst
+ * offset, count}; builds the merged per-(view, bucket) visible lists out of the
+ * all-gathered per-GPU lists (rank order is index order). No reference
+ * counterpart. */
+int vkrhip_concat_ranges(vkrhip_ctx *ctx, const uint32_t *src_dev, uint32_t *dst_dev,
+                         const uint64_t *desc, uint32_t n_desc);
 
 /* ---- host-side mirrors of reference leaf functions (exact op order) -------- */
 /* vkr_frustum_from_matrix, lib/src/math/vkr_frustum.c:44-66 */

@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _gpu_available() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The reference's own code compiled into oracle/_ref (absent off this box)."""
+    from oracle import pyoracle
+    if not pyoracle.have_reference():
+        pytest.skip("oracle/_ref/libvkr_ref.so not built (no reference checkout here)")
+    return pyoracle.Reference()
+
+
+def bits(a):
+    """Bit view for exact float comparison."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.view(np.uint32)
+
+
+def assert_bits_equal(a, b, what=""):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    ne = a.view(np.uint32) != b.view(np.uint32)
+    if ne.any():
+        idx = np.argwhere(ne)[:5]
+        raise AssertionError(f"{what}: {int(ne.sum())} of {ne.size} floats differ bitwise, first at "
+                             f"{idx.tolist()}: {a[tuple(idx[0])]!r} vs {b[tuple(idx[0])]!r}")

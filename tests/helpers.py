@@ -1,0 +1,99 @@
+"""Shared drivers for the parity tests: run one scene through the HIP path (via
+the C ABI) and through the CPU oracle, and compare every output bit for bit."""
+from __future__ import annotations
+
+import numpy as np
+
+from conftest import assert_bits_equal
+
+DIRTY_LOCAL, DIRTY_WORLD, WORLD_UPDATED = 0x01, 0x02, 0x08
+
+
+def view_set(vs, extra_vp=None):
+    """(planes, required, camera_view, projection) for a synth.ViewSet using the
+    library's host-side frustum extraction."""
+    from vulkan_renderer_amd import build_view_set, frustum_from_matrix
+    planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
+    if extra_vp is not None and len(extra_vp):
+        ep = np.stack([frustum_from_matrix(m) for m in extra_vp])
+        planes = np.concatenate([planes, ep])
+        required = np.concatenate([required, np.full(len(extra_vp), 0x4, np.uint32)])
+    return planes, required
+
+
+def oracle_frame(oracle, sc, planes, required, view, projection, partition_capacity=0,
+                 tie_eps=0.0, index_base=0, world=None):
+    """Whole path on the CPU oracle. Returns a dict of every output."""
+    n = sc.n
+    if world is None:
+        local, world, flags, dirty = oracle.scene_update(
+            sc.parent, pos=sc.pos, quat=sc.quat, scale=sc.scale,
+            flags=np.full(n, DIRTY_LOCAL, np.uint8))
+    else:
+        local, flags, dirty = None, None, np.zeros(0, np.uint32)
+    pay = oracle.build_world_payload(world, sc.node, sc.ident, sc.matbits, sc.bounds, view,
+                                     projection, source_index_base=index_base)
+    cls, states, vis, ties = oracle.multiview_cull(
+        pay["gpu_candidates"], planes, required, partition_capacity=partition_capacity,
+        index_base=index_base, tie_eps=tie_eps)
+    return dict(local=local, world=world, flags=flags, dirty=dirty, payload=pay, cls=cls,
+                states=states, visible=vis, ties=ties)
+
+
+def hip_scene_for(sc, views, **kw):
+    from vulkan_renderer_amd import HipScene
+    n_cand = sc.ident.shape[0]
+    hs = HipScene(max_nodes=max(sc.n, 1), max_candidates=max(n_cand, 1), max_views=max(views, 1),
+                  **kw)
+    hs._index_base = kw.get("source_index_base", 0)
+    hs.set_hierarchy(sc.parent, sc.level_offsets)
+    hs.upload_trs(sc.pos, sc.quat, sc.scale)
+    hs.set_candidates(sc.node, sc.ident, sc.matbits, sc.bounds)
+    return hs
+
+
+def compare_frame(hs, ref, sc, check_transform=True, partition_capacity=0):
+    """Compares the last HIP frame of `hs` with the oracle outputs in `ref`."""
+    info = hs.frame_info()
+    pay = ref["payload"]
+    n_cand = sc.ident.shape[0]
+    if check_transform:
+        assert_bits_equal(hs.read_locals(), ref["local"], "local matrices")
+        assert_bits_equal(hs.read_world(), ref["world"], "world matrices")
+        assert (hs.read_node_flags() == ref["flags"]).all(), "node flags"
+        assert info.nodes_updated == ref["dirty"].shape[0]
+    # stats and counts (application.h:745-749,761-762)
+    assert info.objects_tested == int(pay["stats"][0])
+    assert info.objects_culled_camera == int(pay["stats"][1])
+    assert info.objects_without_bounds == int(pay["stats"][2])
+    assert info.gpu_candidate_count == int(pay["counts"][0])
+    assert info.gpu_camera_opaque_candidate_count == int(pay["counts"][1])
+    assert info.transmission_gpu_candidate_count == int(pay["counts"][2])
+    assert info.transparent_draw_count == int(pay["counts"][3])
+    # per-view compaction state and visible lists
+    states = ref["states"]
+    assert len(info.views) == states.shape[0]
+    for v, st in enumerate(info.views):
+        assert (st.execution_ranges == states[v]["execution_ranges"]).all(), f"view {v} ranges"
+        assert (st.bucket_counts == states[v]["bucket_counts"]).all(), f"view {v} counts"
+        assert (st.bucket_cursors == states[v]["bucket_cursors"]).all(), f"view {v} cursors"
+        assert st.visible_count == int(states[v]["visible_count"]), f"view {v} visible_count"
+        assert st.overflow_count == int(states[v]["overflow_count"]), f"view {v} overflow"
+        assert st.near_plane_ties == int(ref["ties"][v]), f"view {v} ties"
+        got = hs.read_visible(v, st.visible_count)
+        assert (got == ref["visible"][v, : st.visible_count]).all(), f"view {v} visible list"
+    # transparent visibility bytes, sorted draws, instances
+    if n_cand:
+        assert (hs.read_transparent_visible() == pay["transparent_visible"]).all()
+    t = info.transparent_draw_count
+    draws, inst, keys, src = hs.read_transparent(t)
+    assert (keys == pay["sort_keys"]).all(), "sorted keys"
+    assert (src.astype(np.uint64) + np.uint64(hs_index_base(hs)) ==
+            pay["sorted_source"].astype(np.uint64)).all(), "sorted source rows"
+    assert draws.tobytes() == pay["draws"].tobytes(), "VkrDrawItem rows"
+    assert inst.tobytes() == pay["instances"].tobytes(), "VkrInstanceDataGPU rows"
+    return info
+
+
+def hs_index_base(hs):
+    return getattr(hs, "_index_base", 0)

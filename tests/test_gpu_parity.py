@@ -1,0 +1,276 @@
+"""HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs. Integer/index outputs and float outputs are compared bit for bit; the
+stated tolerance for world matrices (1e-6 relative) is therefore met with zero
+slack."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from helpers import (DIRTY_LOCAL, DIRTY_WORLD, WORLD_UPDATED, compare_frame, hip_scene_for,
+                     oracle_frame, view_set)
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT, STAGE_CANDIDATES, STAGE_BOUNDS = 1, 2, 4, 8, 16
+
+
+def _synth():
+    from vulkan_renderer_amd import synth
+    return synth
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 255, 256, 257, 1023, 1024, 1025, 5000, 70001])
+def test_flat_single_view(oracle, n):
+    synth = _synth()
+    sc = synth.flat_scene(n, seed=1, blend_fraction=0.3, no_bounds_fraction=0.02)
+    vs = synth.camera_views(far=1200.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+
+
+def test_deep_hierarchy_five_views(oracle):
+    synth = _synth()
+    sc = synth.deep_scene(40000, depth=8, seed=2, fanout=4, roots=5, blend_fraction=0.2,
+                          transmissive_fraction=0.05, no_bounds_fraction=0.01)
+    vs = synth.camera_views(cascades=4, far=600.0)
+    planes, required = view_set(vs)
+    assert planes.shape[0] == 5
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, tie_eps=1e-5)
+    with hip_scene_for(sc, 5, tie_epsilon=1e-5) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        assert sum(v.visible_count for v in info.views) > 1000
+
+
+def test_sixty_four_views(oracle):
+    synth = _synth()
+    sc = synth.flat_scene(20000, seed=7, blend_fraction=0.1)
+    vps, (view, proj) = synth.ring_views(63)
+    vs = synth.camera_views(far=800.0)
+    planes, required = view_set(vs, extra_vp=vps)
+    assert planes.shape[0] == 64
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 64) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+
+
+def test_partition_capacity_overflow(oracle):
+    synth = _synth()
+    sc = synth.flat_scene(30000, seed=3, blend_fraction=0.05)
+    vs = synth.camera_views(far=3000.0, fov_deg=100.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, partition_capacity=500)
+    assert int(ref["states"][0]["overflow_count"]) > 0
+    with hip_scene_for(sc, 1, partition_capacity=500) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+
+
+def test_node_mapping_and_submeshes(oracle):
+    """Several candidate rows (submeshes) per transform, in arbitrary node order."""
+    synth = _synth()
+    sc = synth.deep_scene(3000, depth=5, seed=4, fanout=6, roots=3)
+    rng = np.random.default_rng(5)
+    n_cand = 8000
+    node = rng.integers(0, sc.n, n_cand).astype(np.uint32)
+    ident, matbits, bounds = synth.make_candidates(9, np.arange(n_cand, dtype=np.uint64),
+                                                   blend_fraction=0.25)
+    sc.node, sc.ident, sc.matbits, sc.bounds = node, ident, matbits, bounds
+    vs = synth.camera_views(cascades=2, far=900.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 3) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame(STAGE_TRANSFORM | STAGE_CULL | STAGE_TRANSPARENT | STAGE_CANDIDATES | STAGE_BOUNDS)
+        compare_frame(hs, ref, sc)
+        rows = hs.read_candidates()
+        assert rows.tobytes() == ref["payload"]["gpu_candidates"].tobytes(), "VkrWorldDrawCandidate rows"
+        wb = hs.read_world_bounds()
+        exp = np.stack([oracle.instance_world_bounds(ref["world"][node[i]], bounds[i, :3],
+                                                     ref["payload"]["gpu_candidates"][i]["sphere"][3])
+                        for i in range(0, n_cand, 7)])
+        assert_bits_equal(wb[::7], exp, "instance world bounds")
+
+
+def test_source_index_base(oracle):
+    synth = _synth()
+    sc = synth.flat_scene(9000, seed=6, first=123456, blend_fraction=0.4)
+    vs = synth.camera_views(far=1500.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, index_base=123456)
+    with hip_scene_for(sc, 1, source_index_base=123456) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+
+
+def test_dirty_propagation(oracle):
+    """Only moved nodes and their descendants are recomputed
+    (vkr_scene_system.c:1310-1321)."""
+    synth = _synth()
+    sc = synth.deep_scene(6000, depth=6, seed=8, fanout=5, roots=4)
+    n = sc.n
+    with hip_scene_for(sc, 1) as hs:
+        hs.frame(STAGE_TRANSFORM)
+        info = hs.frame_info()
+        assert info.nodes_updated == n
+        local0, world0, flags0, _ = oracle.scene_update(
+            sc.parent, pos=sc.pos, quat=sc.quat, scale=sc.scale, flags=np.full(n, DIRTY_LOCAL, np.uint8))
+        assert_bits_equal(hs.read_world(), world0, "first frame")
+        # second frame with nothing dirty: nothing moves, WORLD_UPDATED clears
+        hs.frame(STAGE_TRANSFORM)
+        assert hs.frame_info().nodes_updated == 0
+        assert (hs.read_node_flags() == 0).all()
+        # move one level-1 node: its subtree follows
+        lvl1 = int(sc.level_offsets[1]) + 1
+        pos = sc.pos.copy()
+        pos[lvl1, :3] += np.float32(3.5)
+        hs.upload_trs(pos[lvl1:lvl1 + 1], sc.quat[lvl1:lvl1 + 1], sc.scale[lvl1:lvl1 + 1], first=lvl1)
+        hs.frame(STAGE_TRANSFORM)
+        flags1 = np.zeros(n, np.uint8)
+        flags1[lvl1] = DIRTY_LOCAL
+        local1, world1, flags_out, dirty = oracle.scene_update(
+            sc.parent, local=local0, world=world0, flags=flags1, pos=pos, quat=sc.quat, scale=sc.scale)
+        assert 1 < dirty.shape[0] < n
+        assert hs.frame_info().nodes_updated == dirty.shape[0]
+        assert_bits_equal(hs.read_world(), world1, "after partial update")
+        assert_bits_equal(hs.read_locals(), local1, "locals after partial update")
+        assert (hs.read_node_flags() == flags_out).all()
+        # bulk "everything moved" marker
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame(STAGE_TRANSFORM)
+        assert hs.frame_info().nodes_updated == n
+        assert_bits_equal(hs.read_world(), world1, "after mark_all")
+
+
+def test_uploaded_locals_and_unordered_hierarchy(oracle):
+    """Arbitrary parent array -> levelize -> propagate, against the oracle's BFS."""
+    from vulkan_renderer_amd import HipScene, levelize
+    rng = np.random.default_rng(21)
+    n = 5000
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    for i in range(1, n):
+        if rng.uniform() > 0.01:
+            parent[i] = rng.integers(0, i)
+    perm = rng.permutation(n)          # scramble storage order
+    inv = np.argsort(perm)
+    parent_s = np.full(n, 0xFFFFFFFF, np.uint32)
+    for new, old in enumerate(perm):
+        p = parent[old]
+        parent_s[new] = 0xFFFFFFFF if p == 0xFFFFFFFF else inv[p]
+    local_s = rng.uniform(-1.5, 1.5, (n, 16)).astype(np.float32)
+    topo, _, levels = oracle.build_topo_order(parent_s)
+    _, world_s, _, _ = oracle.scene_update(parent_s, local=local_s, flags=np.full(n, DIRTY_WORLD, np.uint8),
+                                           topo=topo)
+    order, new_parent, offsets = levelize(parent_s)
+    assert (order == topo).all() and offsets.shape[0] - 1 == levels
+    with HipScene(max_nodes=n, max_candidates=1) as hs:
+        hs.set_hierarchy(new_parent, offsets)
+        hs.upload_locals(local_s[order])
+        hs.frame(STAGE_TRANSFORM)
+        assert_bits_equal(hs.read_world(), world_s[order], "levelized world matrices")
+
+
+def test_edge_values(oracle):
+    """NaN / zero-scale / behind-camera / equal-depth rows."""
+    synth = _synth()
+    n = 4096
+    sc = synth.flat_scene(n, seed=10, blend_fraction=1.0)
+    sc.pos[:, 2] = -np.abs(sc.pos[:, 2])       # in front of the camera
+    sc.pos[:1500, :3] = sc.pos[0, :3]           # many identical depths (ties broken by index)
+    sc.scale[100:140, :3] = 0.0                 # zero scale: radius 0
+    sc.pos[200:210, 0] = np.nan                 # NaN centre: every compare false => visible
+    sc.pos[300:320, 2] = 50.0                   # behind the camera
+    sc.scale[300:320, :3] = 400.0               # ... but huge: visible with depth clamped to 0
+    sc.bounds[400:420, 8:11] = np.inf           # infinite extent
+    sc.matbits[500:520] &= ~np.uint32(0x10)     # bounds invalid: always visible
+    vs = synth.camera_views(far=2000.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    keys = ref["payload"]["sort_keys"]
+    assert ((keys >> np.uint64(32)) == 0).sum() >= 10      # clamped depths present
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+
+
+def test_empty_scene_candidates(oracle):
+    from vulkan_renderer_amd import HipScene
+    synth = _synth()
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    sc = synth.flat_scene(10, seed=1)
+    with HipScene(max_nodes=10, max_candidates=4) as hs:
+        hs.set_hierarchy(sc.parent, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        hs.set_candidates(None, np.zeros((0, 8), np.uint32), np.zeros(0, np.uint32),
+                          np.zeros((0, 12), np.float32))
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = hs.frame_info()
+        assert info.objects_tested == 0 and info.transparent_draw_count == 0
+        assert info.views[0].visible_count == 0 and info.nodes_updated == 10
+
+
+def test_error_conventions():
+    from vulkan_renderer_amd import HipScene
+    from vulkan_renderer_amd._native import ERR_ARG, ERR_CAPACITY, ERR_STATE, VkrHipError
+    synth = _synth()
+    with HipScene(max_nodes=8, max_candidates=8) as hs:
+        with pytest.raises(VkrHipError) as e:
+            hs.frame()
+        assert e.value.code == ERR_STATE
+        sc = synth.flat_scene(9)
+        with pytest.raises(VkrHipError) as e:
+            hs.set_hierarchy(sc.parent, sc.level_offsets)
+        assert e.value.code == ERR_CAPACITY
+        bad_parent = np.array([0xFFFFFFFF, 5, 0], np.uint32)
+        with pytest.raises(VkrHipError) as e:
+            hs.set_hierarchy(bad_parent, np.array([0, 1, 3], np.uint64))
+        assert e.value.code == ERR_ARG
+
+
+def test_large_properties():
+    """Full-size run (1M, the bench workload): size-independent properties."""
+    synth = _synth()
+    n = 1 << 20
+    sc = synth.flat_scene(n, seed=1)
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = hs.frame_info()
+        st = info.views[0]
+        vis = hs.read_visible(0, st.visible_count)
+        # bucket-major, strictly ascending inside each bucket, bucket matches material
+        sphere, cf = hs.read_candidate_prep()
+        for b in range(4):
+            off, cnt = st.execution_ranges[b]
+            seg = vis[off:off + cnt]
+            assert (np.diff(seg.astype(np.int64)) > 0).all()
+            assert (((cf[seg] >> 4) & 0xF) == b).all()
+        assert st.visible_count == st.bucket_counts.sum()
+        t = info.transparent_draw_count
+        draws, inst, keys, src = hs.read_transparent(t)
+        assert (np.diff(keys.astype(np.float64)) <= 0).all() and np.unique(keys).shape[0] == t
+        assert (keys[:-1] > keys[1:]).all()
+        tv = hs.read_transparent_visible()
+        assert t == int(tv.sum()) and (np.sort(src) == np.flatnonzero(tv)).all()
+        assert (draws["first_instance"] == np.arange(t)).all()
+        assert ((keys & np.uint64(0xFFFFFFFF)) == src.astype(np.uint64) + np.uint64(1)).all()
+        # idempotence: same frame again gives the same lists
+        hs.frame()
+        info2 = hs.frame_info()
+        assert info2.views[0].visible_count == st.visible_count
+        assert (hs.read_visible(0, st.visible_count) == vis).all()
+        assert (hs.read_transparent(t)[2] == keys).all()

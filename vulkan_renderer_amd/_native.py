@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_read_locals", "vkrhip_read_node_flags", "vkrhip_read_visible",
     "vkrhip_read_transparent_visible", "vkrhip_read_transparent", "vkrhip_read_candidates",
     "vkrhip_read_world_bounds", "vkrhip_read_candidate_prep", "vkrhip_set_profiling",
-    "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_frustum_from_matrix",
+    "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize",
 ]
@@ -157,9 +157,10 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_read_candidates.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_world_bounds.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_candidate_prep.argtypes = [vp, u64, u64, vp, vp]
-    L.vkrhip_set_profiling.argtypes = [vp, C.c_int]
+    L.vkrhip_set_profiling.argtypes = [vp, u32]
     L.vkrhip_get_timers.argtypes = [vp, vp, vp, C.c_int]
     L.vkrhip_merge_runs.argtypes = [vp, u32, vp, vp, vp]
+    L.vkrhip_concat_ranges.argtypes = [vp, vp, vp, vp, u32]
     L.vkrhip_frustum_from_matrix.argtypes = [vp, vp]
     L.vkrhip_frustum_from_matrix.restype = None
     L.vkrhip_frustum_from_view_projection.argtypes = [vp, vp, vp]

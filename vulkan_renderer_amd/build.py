@@ -13,9 +13,10 @@ HEADERS = ["device_math.hpp", "k_transform.hpp", "k_cull.hpp", "k_sort.hpp"]
 
 # -ffp-contract=off: the reference fuses multiply-add only inside mat4_mul
 # (lib/src/math/mat.h:1145-1163); hipcc's default would fuse everywhere and
-# change result bits.
+# change result bits. Square roots must be correctly rounded (sqrtf on the host).
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+    "--offload-arch=gfx950", "-O3", "-ffp-contract=off",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-std=c++17",
     "-Wall", "-Wno-unused-function",
 ]
 

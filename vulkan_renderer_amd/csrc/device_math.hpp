@@ -19,13 +19,11 @@ __host__ __device__ __forceinline__ float fma_rn(float a, float b, float c) {
   return __builtin_fmaf(a, b, c);
 }
 
-__host__ __device__ __forceinline__ float sqrt_rn(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fsqrt_rn(x);
-#else
-  return __builtin_sqrtf(x);
-#endif
-}
+// Correctly rounded square root. On the device this relies on
+// -fhip-fp32-correctly-rounded-divide-sqrt (hipcc's default, passed explicitly
+// by the build): __builtin_sqrtf then expands to the IEEE sequence, whereas
+// HIP's __fsqrt_rn maps to the 1-ulp native v_sqrt_f32.
+__host__ __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 
 // vkr_simd_dot3_f32x4, lib/src/math/vkr_simd.h:914-917: (x*x' + y*y') + (z*z' + 0)
 __host__ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by,

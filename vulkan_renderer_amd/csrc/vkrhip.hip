@@ -101,9 +101,10 @@ struct vkrhip_ctx {
   // merge scratch
   DevBuf<const uint64_t *> merge_ptrs;
   DevBuf<uint64_t> merge_lens;
+  DevBuf<uint64_t> concat_desc;
 
   // timing
-  bool profiling = false;
+  uint32_t profiling = 0;  // bit i: time stage i
   std::vector<EventPair> pending;
   std::vector<EventPair> free_events;
   double timer_ms[VKRHIP_TIMER_COUNT] = {};
@@ -174,7 +175,7 @@ struct StageTimer {
   EventPair ev{};
   bool on = false;
   StageTimer(vkrhip_ctx *ctx, int timer) : c(ctx) {
-    if (!c->profiling) return;
+    if (!(c->profiling & (1u << timer))) return;
     if (!c->free_events.empty()) {
       ev = c->free_events.back();
       c->free_events.pop_back();
@@ -340,6 +341,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->instances);
   dev_free(c->merge_ptrs);
   dev_free(c->merge_lens);
+  dev_free(c->concat_desc);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -920,9 +922,9 @@ int vkrhip_read_candidate_prep(vkrhip_ctx *c, uint64_t first, uint64_t count, fl
 // ---------------------------------------------------------------------------
 // timing
 // ---------------------------------------------------------------------------
-int vkrhip_set_profiling(vkrhip_ctx *c, int enabled) {
+int vkrhip_set_profiling(vkrhip_ctx *c, uint32_t timer_mask) {
   if (!c) return VKRHIP_ERR_ARG;
-  c->profiling = enabled != 0;
+  c->profiling = timer_mask;
   return VKRHIP_OK;
 }
 
@@ -981,9 +983,34 @@ __global__ __launch_bounds__(256) void k_merge_runs(const uint64_t *const *runs,
   out[pos] = key;
 }
 
+// Segmented copy: descriptor d = {src offset, dst offset, count} in elements.
+__global__ __launch_bounds__(256) void k_concat_ranges(const uint32_t *src, uint32_t *dst,
+                                                       const uint64_t *desc) {
+  const uint64_t s = desc[blockIdx.x * 3u + 0];
+  const uint64_t d = desc[blockIdx.x * 3u + 1];
+  const uint64_t n = desc[blockIdx.x * 3u + 2];
+  for (uint64_t k = (uint64_t)blockIdx.y * 256u + threadIdx.x; k < n; k += (uint64_t)gridDim.y * 256u)
+    dst[d + k] = src[s + k];
+}
+
 }  // namespace vkr
 
 extern "C" {
+
+int vkrhip_concat_ranges(vkrhip_ctx *c, const uint32_t *src_dev, uint32_t *dst_dev,
+                         const uint64_t *desc, uint32_t n_desc) {
+  if (!c || !src_dev || !dst_dev || (!desc && n_desc)) return VKRHIP_ERR_ARG;
+  if (n_desc == 0) return VKRHIP_OK;
+  TRY(bind_device(c));
+  TRY(dev_alloc(c, c->concat_desc, (size_t)n_desc * 3));
+  HIP_TRY(c, hipMemcpyAsync(c->concat_desc.p, desc, (size_t)n_desc * 24, hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // desc is caller memory
+  hipLaunchKernelGGL(k_concat_ranges, dim3(n_desc, 16), dim3(256), 0, c->stream, src_dev, dst_dev,
+                     c->concat_desc.p);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
 
 int vkrhip_merge_runs(vkrhip_ctx *c, uint32_t g, const uint64_t *const *runs_keys,
                       const uint64_t *lengths, uint64_t *out_keys_dev) {

@@ -274,8 +274,17 @@ class HipScene:
         return sphere, flags
 
     # ---- timing ---------------------------------------------------------
-    def set_profiling(self, enabled: bool) -> None:
-        self._ok(self.lib.vkrhip_set_profiling(self.ctx, int(enabled)))
+    def set_profiling(self, stages=None) -> None:
+        """stages: None/False = off, True = all, or an iterable of timer names."""
+        if not stages:
+            mask = 0
+        elif stages is True:
+            mask = (1 << len(N.TIMER_NAMES)) - 1
+        else:
+            mask = 0
+            for name in stages:
+                mask |= 1 << N.TIMER_NAMES.index(name)
+        self._ok(self.lib.vkrhip_set_profiling(self.ctx, mask))
 
     def timers(self, reset: bool = False) -> dict:
         ms = np.zeros(len(N.TIMER_NAMES), np.float64)
@@ -289,6 +298,12 @@ class HipScene:
         lens = np.ascontiguousarray(lengths, dtype=np.uint64)
         self._ok(self.lib.vkrhip_merge_runs(self.ctx, g, C.cast(ptrs, C.c_void_p), N.ptr(lens),
                                             out_ptr))
+
+
+    def concat_ranges(self, src_ptr: int, dst_ptr: int, desc) -> None:
+        desc = np.ascontiguousarray(desc, dtype=np.uint64).reshape(-1, 3)
+        self._ok(self.lib.vkrhip_concat_ranges(self.ctx, src_ptr, dst_ptr, N.ptr(desc),
+                                               desc.shape[0]))
 
 
 # ---- host-side leaf mirrors ---------------------------------------------
