@@ -46,13 +46,22 @@ WORKLOADS = {
 # Algorithmic HBM bytes per unit for each kernel of the frame:
 #   transform: local 64 + parent index 4 (non-root) + flags 1+1 + world 64
 #   classify : world 64 + sphere 16 + flags 4 in; view-mask words 4*W + visible byte 1 out
+#   fused    : both, minus the re-read of world (it is classified in registers)
 def kernel_bytes(name: str, n: int, depth: int, views: int) -> float:
     words = (views + 31) // 32
+    transform = 64 + 64 + 2 + (4 if depth > 1 else 0)
+    classify_in, classify_out = 64 + 16 + 4, 4 * words + 1
     if name == "transform":
-        return n * (64 + 64 + 2 + (4 if depth > 1 else 0))
+        return n * transform
     if name == "classify":
-        return n * (64 + 16 + 4 + 4 * words + 1)
+        return n * (classify_in + classify_out)
+    if name == "fused":
+        return n * (transform + classify_in - 64 + classify_out)
     raise KeyError(name)
+
+
+KERNEL_NAMES = {"transform": "k_propagate_level", "classify": "k_classify",
+                "fused": "k_propagate_classify"}
 
 
 def build_scene(workload: dict, rank: int, seed: int):
@@ -146,7 +155,7 @@ def main() -> int:
         step()
     fence()
     warm = hs.timers(reset=True)
-    dominant = max(("transform", "classify"), key=lambda k: warm[k][0])
+    dominant = max(("transform", "classify", "fused"), key=lambda k: warm[k][0])
     hs.set_profiling([dominant])
 
     fence()
@@ -168,14 +177,11 @@ def main() -> int:
 
     dom_ms, dom_n = timers[dominant]
     dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
-    if dominant == "transform":
-        launches = len(sc.level_offsets) - 1
-    else:
-        launches = 1
+    launches = 1 if dominant == "classify" else len(sc.level_offsets) - 1
     alg_bytes = kernel_bytes(dominant, n, workload["depth"], views)
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "k_propagate_level" if dominant == "transform" else "k_classify",
+        "bound": "hbm", "kernel": KERNEL_NAMES[dominant],
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "avg_launch_us": round(dom_avg_s * 1e6 / launches, 2),

@@ -207,11 +207,11 @@ int vkrhip_read_candidate_prep(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
                                float *sphere4, uint32_t *flags_bucket);
 
 /* ---- per-stage device timing (HIP events on the context's stream) ---------- */
-#define VKRHIP_TIMER_TRANSFORM 0
-#define VKRHIP_TIMER_CLASSIFY 1
-#define VKRHIP_TIMER_SCAN 2
-#define VKRHIP_TIMER_SCATTER 3
-#define VKRHIP_TIMER_KEYGEN 4
+#define VKRHIP_TIMER_TRANSFORM 0 /* stand-alone level launches */
+#define VKRHIP_TIMER_CLASSIFY 1  /* stand-alone classify */
+#define VKRHIP_TIMER_FUSED 2     /* transform + classify in one launch per level */
+#define VKRHIP_TIMER_SCAN 3
+#define VKRHIP_TIMER_SCATTER 4
 #define VKRHIP_TIMER_SORT 5
 #define VKRHIP_TIMER_EMIT 6
 #define VKRHIP_TIMER_CANDIDATES 7

@@ -274,3 +274,66 @@ def test_large_properties():
         assert info2.views[0].visible_count == st.visible_count
         assert (hs.read_visible(0, st.visible_count) == vis).all()
         assert (hs.read_transparent(t)[2] == keys).all()
+
+
+def test_large_transparent_sort(oracle):
+    """More visible blend rows than the single-workgroup sort holds: the
+    multi-pass histogram/scan/scatter path."""
+    synth = _synth()
+    sc = synth.flat_scene(150000, seed=12, blend_fraction=1.0)
+    sc.pos[::3, :3] = sc.pos[0, :3]            # a third of the rows share one depth
+    vs = synth.camera_views(far=4000.0, fov_deg=110.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    assert ref["payload"]["draws"].shape[0] > 3 * 8192
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+
+
+def test_separate_stages(oracle):
+    """Transform in one frame call, cull + sort in another: the stand-alone
+    classify kernel with the identity candidate->node mapping."""
+    synth = _synth()
+    sc = synth.deep_scene(30000, depth=6, seed=14, fanout=5, roots=6, blend_fraction=0.3)
+    vs = synth.camera_views(cascades=3, far=900.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 4) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame(STAGE_TRANSFORM)
+        assert hs.frame_info().nodes_updated == sc.n
+        hs.frame(STAGE_CULL | STAGE_TRANSPARENT)
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert_bits_equal(hs.read_world(), ref["world"], "world matrices")
+
+
+def test_sort_path_misprediction(oracle):
+    """The host picks the sort path from an earlier frame's transparent count.
+    A frame with few visible blend rows followed by one with many makes the
+    single-workgroup sort handle a count beyond its LDS capacity (streaming
+    through global memory); the frame after that uses the multi-pass path."""
+    synth = _synth()
+    sc = synth.flat_scene(120000, seed=15, blend_fraction=1.0)
+    narrow = synth.camera_views(far=30.0, fov_deg=20.0)
+    wide = synth.camera_views(far=4000.0, fov_deg=110.0)
+    p_n, r_n = view_set(narrow)
+    p_w, r_w = view_set(wide)
+    ref_n = oracle_frame(oracle, sc, p_n, r_n, narrow.view, narrow.projection)
+    ref_w = oracle_frame(oracle, sc, p_w, r_w, wide.view, wide.projection)
+    assert ref_n["payload"]["draws"].shape[0] < 2000
+    assert ref_w["payload"]["draws"].shape[0] > 20000
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(p_n, r_n, narrow.view)
+        hs.frame()
+        compare_frame(hs, ref_n, sc)                 # count small, small path
+        hs.set_views(p_w, r_w, wide.view)
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame()                                   # predicted small, actually large
+        compare_frame(hs, ref_w, sc, check_transform=False)
+        hs.frame()                                   # predicted large: multi-pass kernels
+        compare_frame(hs, ref_w, sc, check_transform=False)
+        hs.set_views(p_n, r_n, narrow.view)
+        hs.frame()                                   # predicted large, actually small
+        compare_frame(hs, ref_n, sc, check_transform=False)

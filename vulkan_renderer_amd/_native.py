@@ -27,7 +27,7 @@ STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT = 0x1, 0x2, 0x4
 STAGE_CANDIDATES, STAGE_WORLD_BOUNDS = 0x8, 0x10
 STAGE_ALL = 0x7
 
-TIMER_NAMES = ["transform", "classify", "scan", "scatter", "keygen", "sort", "emit",
+TIMER_NAMES = ["transform", "classify", "fused", "scan", "scatter", "sort", "emit",
                "candidates", "frame"]
 
 EXPORTED_SYMBOLS = [

@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvkrhip.so")
 SOURCES = ["vkrhip.hip", "vkrhip_host.cpp"]
-HEADERS = ["device_math.hpp", "k_transform.hpp", "k_cull.hpp", "k_sort.hpp"]
+HEADERS = ["device_math.hpp", "k_transform.hpp", "k_cull.hpp", "k_fused.hpp", "k_sort.hpp"]
 
 # -ffp-contract=off: the reference fuses multiply-add only inside mat4_mul
 # (lib/src/math/mat.h:1145-1163); hipcc's default would fuse everywhere and

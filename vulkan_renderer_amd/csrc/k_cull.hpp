@@ -5,14 +5,17 @@
 // (lib/src/renderer/shaders/vulkan/slang/world/deferred.slang:225-238,305-420,
 // HZB branch excluded) evaluated with the CPU helpers' arithmetic
 // (lib/src/renderer/vkr_visibility.c:37-50, lib/src/math/vkr_frustum.c:68-84),
-// plus the ordinary-blend camera cull and counters of
-// application_build_world_payload (lib/src/application.h:730-806).
+// plus the ordinary-blend camera cull, depth key and counters of
+// application_build_world_payload (lib/src/application.h:573-587,730-806).
 //
 // Three launches:
-//   k_classify  one thread per candidate; reads world 64 B + sphere 16 B +
-//               flags 4 B once for ALL views (planes are wave-uniform scalar
-//               loads), writes one visibility bit per view and per-tile
-//               survivor counts per (view, bucket) row.
+//   classify    one thread per candidate; the world matrix (64 B), local sphere
+//               (16 B) and flags (4 B) are read once for ALL views (planes are
+//               wave-uniform scalar loads). Writes one visibility bit per view,
+//               the blend-row visibility byte and sort key, and adds per-tile
+//               survivor counts per (view, bucket) row. It exists stand-alone
+//               (k_classify) and fused behind the transform of the same node
+//               (k_fused.hpp).
 //   k_scan      exclusive scan of the tile counts of every row, then the
 //               4-bucket prefix of vk_gpu_draw_prefix per view.
 //   k_scatter   re-reads the bit masks (not the matrices) and writes candidate
@@ -26,7 +29,7 @@ namespace vkr {
 
 constexpr int CULL_BLOCK = 256;
 constexpr int CULL_ROUNDS = 4;
-constexpr int CULL_TILE = CULL_BLOCK * CULL_ROUNDS;  // candidates per block
+constexpr int CULL_TILE = CULL_BLOCK * CULL_ROUNDS;  // candidates per count tile
 constexpr int CULL_MAX_VIEWS = 64;
 constexpr int CULL_MAX_ROWS = CULL_MAX_VIEWS * 4 + 1;  // (view,bucket) rows + transparent row
 constexpr int MAT_LDS_STRIDE = 5;  // float4 per staged matrix (80 B: conflict-free b128 reads)
@@ -51,6 +54,12 @@ enum : int {
   CNT_TRANSPARENT_TOTAL = 6,  // before the clamp
   CNT_COUNT = 8
 };
+// Counters that every block adds to are kept in STAT_SHARDS copies (block b uses
+// copy b % STAT_SHARDS) and summed on the host: thousands of device-scope
+// atomics on one word serialise at ~90 per microsecond.
+constexpr uint32_t STAT_SHARDS = 64;
+constexpr uint32_t TIE_SHARDS = 16;
+__device__ __forceinline__ uint32_t stat_shard() { return (blockIdx.x % STAT_SHARDS) * CNT_COUNT; }
 
 struct CompactionState {  // VkrGpuDrawCompactionState, vkr_gpu_abi.h:95-103
   uint32_t execution_ranges[4][2];
@@ -106,39 +115,178 @@ struct CullArgs {
   const float4 *planes;    // views x 6
   const float *tie_eps;    // views x 6: eps * max(1,|d|)
   const uint32_t *required;
+  const float4 *view;      // camera view matrix columns
   uint32_t *masks;         // [word][mask_stride]
   uint8_t *tvis;           // transparent_visible
+  uint64_t *tkey;          // sort key of visible blend rows (sparse, per candidate)
   float4 *world_bounds;    // optional (cx,cy,cz,r) per candidate
-  uint32_t *tile_counts;   // [row][tiles_stride]
-  uint32_t *counters;
-  unsigned long long *ties;  // per view
+  uint32_t *tile_counts;   // [row][tiles_stride], zeroed before the frame
+  uint32_t *counters;        // [STAT_SHARDS][CNT_COUNT]
+  unsigned long long *ties;  // [TIE_SHARDS][CULL_MAX_VIEWS]
   uint64_t n;
   uint64_t mask_stride;
   uint64_t tiles_stride;
+  uint64_t index_base;
   uint32_t views;
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// Loads the matrices of candidates [base, base+256) for the block: coalesced
-// 16-byte loads staged through LDS when candidate i uses node i, a per-thread
-// gather otherwise.
-template <bool IDENTITY>
-__device__ __forceinline__ Mat4 load_model(const CullArgs &a, float4 *s_mat, uint64_t base,
-                                           uint64_t i, bool valid) {
+// LDS accumulators of one classify block.
+struct CullShared {
+  uint32_t cnt[CULL_MAX_ROWS];
+  uint32_t stat[4];
+  uint32_t ties[CULL_MAX_VIEWS];
+};
+
+__device__ __forceinline__ void cull_shared_clear(CullShared &s, uint32_t views) {
+  const uint32_t t = threadIdx.x;
+  for (uint32_t r = t; r < views * 4u + 1u; r += blockDim.x) s.cnt[r] = 0u;
+  if (t < 4) s.stat[t] = 0u;
+  for (uint32_t r = t; r < views; r += blockDim.x) s.ties[r] = 0u;
+}
+
+// Classifies one candidate against every view. Must be called by all threads of
+// the wave (it votes). `valid` lanes own candidate i with model matrix m.
+template <bool TIES, bool BOUNDS_OUT>
+__device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared &s, uint64_t i,
+                                                   bool valid, const Mat4 &m, float4 ls,
+                                                   uint32_t cf) {
+  const bool leader = lane_id() == 0;
+  // world sphere: vkr_visibility.c:40-49 / deferred.slang:325-333
+  const float3 c = mat4_mul_point(m, ls.x, ls.y, ls.z);
+  const float radius = ls.w * max_basis_length(m);
+  if (BOUNDS_OUT && valid) a.world_bounds[i] = make_float4(c.x, c.y, c.z, radius);
+
+  const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
+  const bool bounds_valid = (cf & CF_BOUNDS_VALID) != 0;
+
+  // ordinary blend rows: application.h:790-803 (camera frustum = view 0 planes)
+  const bool blend_row = valid && (cf & CF_BLEND) && !(cf & CF_TRANSMISSIVE);
+  bool tv = false;
+  if (blend_row) tv = bounds_valid ? sphere_visible(a.planes, c.x, c.y, c.z, radius) : true;
+  if (valid) a.tvis[i] = tv ? 1u : 0u;
+  if (tv) {
+    // application_transparent_depth + application_pack_transparent_sort_key,
+    // application.h:573-587. The world centre is the one computed above.
+    Mat4 view;
+    view.c[0] = a.view[0];
+    view.c[1] = a.view[1];
+    view.c[2] = a.view[2];
+    view.c[3] = a.view[3];
+    const float vz = mat4_mul_vec4_z(view, c.x, c.y, c.z, 1.0f);
+    float depth = -vz;
+    depth = depth > 0.0f ? depth : 0.0f;
+    const uint32_t tie_breaker = (uint32_t)(a.index_base + i) + 1u;
+    a.tkey[i] = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)tie_breaker;
+  }
+  {
+    const unsigned long long mt = __ballot(tv);
+    const unsigned long long mc = __ballot(blend_row && !tv);
+    const unsigned long long mb = __ballot(valid && !bounds_valid);
+    const unsigned long long mo = __ballot(valid && (cf & CF_CAMERA_OPAQUE));
+    const unsigned long long mx = __ballot(valid && (cf & CF_TRANSMISSIVE));
+    if (leader) {
+      if (mt) atomicAdd(&s.cnt[a.views * 4u], (uint32_t)__popcll(mt));
+      if (mb) atomicAdd(&s.stat[0], (uint32_t)__popcll(mb));
+      if (mc) atomicAdd(&s.stat[1], (uint32_t)__popcll(mc));
+      if (mo) atomicAdd(&s.stat[2], (uint32_t)__popcll(mo));
+      if (mx) atomicAdd(&s.stat[3], (uint32_t)__popcll(mx));
+    }
+  }
+
+  // views: deferred.slang:316-351
+  const uint32_t words = (a.views + 31u) >> 5;
+  for (uint32_t w = 0; w < words; ++w) {
+    uint32_t bits = 0u;
+    const uint32_t vend = min(a.views, (w + 1u) * 32u);
+    for (uint32_t v = w * 32u; v < vend; ++v) {
+      const uint32_t req = a.required[v];
+      bool pass = valid && bucket < 4u && (cf & req) == req;
+      bool tie = false;
+      if (pass && bounds_valid) {
+        pass = sphere_visible(a.planes + v * 6u, c.x, c.y, c.z, radius);
+        if (TIES) {
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            const float4 pl = a.planes[v * 6u + p];
+            const float dist = dot3(pl.x, pl.y, pl.z, c.x, c.y, c.z) + pl.w;
+            tie = tie || (fabsf(dist + radius) <= a.tie_eps[v * 6u + p]);
+          }
+        }
+      }
+      if (TIES) {
+        const unsigned long long mtie = __ballot(tie);
+        if (leader && mtie) atomicAdd(&s.ties[v], (uint32_t)__popcll(mtie));
+      }
+      if (pass) bits |= 1u << (v & 31u);
+#pragma unroll
+      for (uint32_t q = 0; q < 4u; ++q) {
+        const unsigned long long mq = __ballot(pass && bucket == q);
+        if (leader && mq) atomicAdd(&s.cnt[v * 4u + q], (uint32_t)__popcll(mq));
+      }
+    }
+    if (valid) a.masks[(uint64_t)w * a.mask_stride + i] = bits;
+  }
+}
+
+// Adds the block's accumulators to the global tile counts / counters. All
+// candidates of the block must lie in count tile `tile`.
+template <bool TIES>
+__device__ __forceinline__ void cull_shared_flush(const CullArgs &a, CullShared &s,
+                                                  uint64_t tile) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t rows = a.views * 4u + 1u;
+  __syncthreads();
+  for (uint32_t r = t; r < rows; r += blockDim.x)
+    if (s.cnt[r]) atomicAdd(&a.tile_counts[(uint64_t)r * a.tiles_stride + tile], s.cnt[r]);
+  if (t == 0) {
+    uint32_t *shard = a.counters + stat_shard();
+    if (s.stat[0]) atomicAdd(&shard[CNT_WITHOUT_BOUNDS], s.stat[0]);
+    if (s.stat[1]) atomicAdd(&shard[CNT_CULLED_CAMERA], s.stat[1]);
+    if (s.stat[2]) atomicAdd(&shard[CNT_CAMERA_OPAQUE], s.stat[2]);
+    if (s.stat[3]) atomicAdd(&shard[CNT_TRANSMISSION], s.stat[3]);
+  }
+  if (TIES)
+    for (uint32_t r = t; r < a.views; r += blockDim.x)
+      if (s.ties[r])
+        atomicAdd(&a.ties[(blockIdx.x % TIE_SHARDS) * CULL_MAX_VIEWS + r],
+                  (unsigned long long)s.ties[r]);
+}
+
+// Stand-alone classify: one block per 256 candidates. With the identity
+// candidate->node mapping the matrices arrive as coalesced 16-byte loads staged
+// through LDS (thread t then reads its own four columns); otherwise each thread
+// gathers its node's matrix.
+template <bool IDENTITY, bool TIES, bool BOUNDS_OUT>
+__global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
+  __shared__ float4 s_mat[IDENTITY ? CULL_BLOCK * MAT_LDS_STRIDE : 1];
+  __shared__ CullShared s;
+  const uint32_t t = threadIdx.x;
+  cull_shared_clear(s, a.views);
+
+  const uint64_t base = (uint64_t)blockIdx.x * CULL_BLOCK;
+  const uint64_t i = base + t;
+  const bool valid = i < a.n;
+  float4 ls = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t cf = 0xf0u;  // invalid bucket: fails every gate
+  if (valid) {
+    ls = a.sphere[i];
+    cf = a.cflags[i];
+  }
   Mat4 m;
   if (IDENTITY) {
-    const uint32_t t = threadIdx.x;
     const uint64_t total4 = a.n * 4u;
-    const uint64_t base4 = base * 4u;
-    __syncthreads();  // previous round's readers are done
+    float4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint32_t l = t + 256u * (uint32_t)k;  // float4 index inside the tile
-      const uint64_t g = base4 + l;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < total4) v = a.world[g];
-      s_mat[(l >> 2) * MAT_LDS_STRIDE + (l & 3u)] = v;
+      const uint64_t g = base * 4u + t + 256u * (uint32_t)k;
+      v[k] = g < total4 ? a.world[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t l = t + 256u * (uint32_t)k;
+      s_mat[(l >> 2) * MAT_LDS_STRIDE + (l & 3u)] = v[k];
     }
     __syncthreads();
     const float4 *p = s_mat + t * MAT_LDS_STRIDE;
@@ -147,6 +295,7 @@ __device__ __forceinline__ Mat4 load_model(const CullArgs &a, float4 *s_mat, uin
     m.c[2] = p[2];
     m.c[3] = p[3];
   } else {
+    __syncthreads();  // s cleared
     if (valid) {
       const float4 *p = a.world + (uint64_t)a.node[i] * 4u;
       m.c[0] = p[0];
@@ -157,117 +306,12 @@ __device__ __forceinline__ Mat4 load_model(const CullArgs &a, float4 *s_mat, uin
       m.c[0] = m.c[1] = m.c[2] = m.c[3] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  return m;
-}
-
-template <bool IDENTITY, bool TIES, bool BOUNDS_OUT>
-__global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
-  __shared__ float4 s_mat[IDENTITY ? CULL_BLOCK * MAT_LDS_STRIDE : 1];
-  __shared__ uint32_t s_cnt[CULL_MAX_ROWS];
-  __shared__ uint32_t s_stat[4];
-  __shared__ uint32_t s_ties[TIES ? CULL_MAX_VIEWS : 1];
-
-  const uint32_t t = threadIdx.x;
-  const uint32_t rows = a.views * 4u + 1u;
-  for (uint32_t r = t; r < rows; r += CULL_BLOCK) s_cnt[r] = 0u;
-  if (t < 4) s_stat[t] = 0u;
-  if (TIES)
-    for (uint32_t r = t; r < a.views; r += CULL_BLOCK) s_ties[r] = 0u;
-  __syncthreads();
-
-  const uint64_t tile = blockIdx.x;
-  const bool leader = lane_id() == 0;
-  const uint32_t words = (a.views + 31u) >> 5;
-
-  for (int round = 0; round < CULL_ROUNDS; ++round) {
-    const uint64_t base = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK;
-    if (base >= a.n) break;  // uniform across the block
-    const uint64_t i = base + t;
-    const bool valid = i < a.n;
-    const Mat4 m = load_model<IDENTITY>(a, s_mat, base, i, valid);
-    float4 ls = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t cf = 0xf0u;  // invalid bucket: fails every gate
-    if (valid) {
-      ls = a.sphere[i];
-      cf = a.cflags[i];
-    }
-    // world sphere: vkr_visibility.c:40-49 / deferred.slang:325-333
-    const float3 c = mat4_mul_point(m, ls.x, ls.y, ls.z);
-    const float radius = ls.w * max_basis_length(m);
-    if (BOUNDS_OUT && valid) a.world_bounds[i] = make_float4(c.x, c.y, c.z, radius);
-
-    const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
-    const bool bounds_valid = (cf & CF_BOUNDS_VALID) != 0;
-
-    // ordinary blend rows: application.h:790-803 (camera frustum = view 0 planes)
-    const bool blend_row = valid && (cf & CF_BLEND) && !(cf & CF_TRANSMISSIVE);
-    bool tv = false;
-    if (blend_row) tv = bounds_valid ? sphere_visible(a.planes, c.x, c.y, c.z, radius) : true;
-    if (valid) a.tvis[i] = tv ? 1u : 0u;
-    {
-      const unsigned long long mt = __ballot(tv);
-      const unsigned long long mc = __ballot(blend_row && !tv);
-      const unsigned long long mb = __ballot(valid && !bounds_valid);
-      const unsigned long long mo = __ballot(valid && (cf & CF_CAMERA_OPAQUE));
-      const unsigned long long mx = __ballot(valid && (cf & CF_TRANSMISSIVE));
-      if (leader) {
-        if (mt) atomicAdd(&s_cnt[a.views * 4u], (uint32_t)__popcll(mt));
-        if (mb) atomicAdd(&s_stat[0], (uint32_t)__popcll(mb));
-        if (mc) atomicAdd(&s_stat[1], (uint32_t)__popcll(mc));
-        if (mo) atomicAdd(&s_stat[2], (uint32_t)__popcll(mo));
-        if (mx) atomicAdd(&s_stat[3], (uint32_t)__popcll(mx));
-      }
-    }
-
-    // views: deferred.slang:316-351
-    for (uint32_t w = 0; w < words; ++w) {
-      uint32_t bits = 0u;
-      const uint32_t vend = min(a.views, (w + 1u) * 32u);
-      for (uint32_t v = w * 32u; v < vend; ++v) {
-        const uint32_t req = a.required[v];
-        bool pass = valid && bucket < 4u && (cf & req) == req;
-        bool tie = false;
-        if (pass && bounds_valid) {
-          pass = sphere_visible(a.planes + v * 6u, c.x, c.y, c.z, radius);
-          if (TIES) {
-#pragma unroll
-            for (int p = 0; p < 6; ++p) {
-              const float4 pl = a.planes[v * 6u + p];
-              const float dist = dot3(pl.x, pl.y, pl.z, c.x, c.y, c.z) + pl.w;
-              tie = tie || (fabsf(dist + radius) <= a.tie_eps[v * 6u + p]);
-            }
-          }
-        }
-        if (TIES) {
-          const unsigned long long mtie = __ballot(tie);
-          if (leader && mtie) atomicAdd(&s_ties[v], (uint32_t)__popcll(mtie));
-        }
-        if (pass) bits |= 1u << (v & 31u);
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-          const unsigned long long mq = __ballot(pass && bucket == q);
-          if (leader && mq) atomicAdd(&s_cnt[v * 4u + q], (uint32_t)__popcll(mq));
-        }
-      }
-      if (valid) a.masks[(uint64_t)w * a.mask_stride + i] = bits;
-    }
-  }
-  __syncthreads();
-  for (uint32_t r = t; r < rows; r += CULL_BLOCK)
-    a.tile_counts[(uint64_t)r * a.tiles_stride + tile] = s_cnt[r];
-  if (t == 0) {
-    if (s_stat[0]) atomicAdd(&a.counters[CNT_WITHOUT_BOUNDS], s_stat[0]);
-    if (s_stat[1]) atomicAdd(&a.counters[CNT_CULLED_CAMERA], s_stat[1]);
-    if (s_stat[2]) atomicAdd(&a.counters[CNT_CAMERA_OPAQUE], s_stat[2]);
-    if (s_stat[3]) atomicAdd(&a.counters[CNT_TRANSMISSION], s_stat[3]);
-  }
-  if (TIES)
-    for (uint32_t r = t; r < a.views; r += CULL_BLOCK)
-      if (s_ties[r]) atomicAdd(&a.ties[r], (unsigned long long)s_ties[r]);
+  classify_candidate<TIES, BOUNDS_OUT>(a, s, i, valid, m, ls, cf);
+  cull_shared_flush<TIES>(a, s, base / CULL_TILE);
 }
 
 // ---------------------------------------------------------------------------
-// Block-wide exclusive scan helper (1024 threads, 16 waves).
+// Block-wide exclusive scan helpers (1024 threads, 16 waves).
 // ---------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 1024;
 
@@ -299,6 +343,46 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
   return wave_base + inc - v;
 }
 
+// Four independent scans at once (the four bucket rows of a view).
+__device__ __forceinline__ uint4 block_exclusive_scan4(uint4 v, uint4 *s_wave4, uint4 *total) {
+  const uint32_t w = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  uint4 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t ux = __shfl_up(inc.x, d, 64);
+    const uint32_t uy = __shfl_up(inc.y, d, 64);
+    const uint32_t uz = __shfl_up(inc.z, d, 64);
+    const uint32_t uw = __shfl_up(inc.w, d, 64);
+    if ((int)lane_id() >= d) {
+      inc.x += ux;
+      inc.y += uy;
+      inc.z += uz;
+      inc.w += uw;
+    }
+  }
+  __syncthreads();
+  if (lane_id() == 63) s_wave4[w] = inc;
+  __syncthreads();
+  uint4 base = make_uint4(0, 0, 0, 0), sum = make_uint4(0, 0, 0, 0);
+  for (uint32_t k = 0; k < nw; ++k) {
+    const uint4 x = s_wave4[k];
+    if (k < w) {
+      base.x += x.x;
+      base.y += x.y;
+      base.z += x.z;
+      base.w += x.w;
+    }
+    sum.x += x.x;
+    sum.y += x.y;
+    sum.z += x.z;
+    sum.w += x.w;
+  }
+  *total = sum;
+  return make_uint4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z,
+                    base.w + inc.w - v.w);
+}
+
 struct ScanArgs {
   uint32_t *tile_counts;  // [row][tiles_stride], scanned in place
   CompactionState *states;
@@ -309,31 +393,40 @@ struct ScanArgs {
   uint32_t partition_capacity;  // 0 = unlimited
   uint64_t visible_capacity;
   uint64_t transparent_capacity;
+  uint32_t *host_hint;  // pinned host word: last frame's transparent count (may be null)
 };
-
-__device__ __forceinline__ uint32_t scan_row(uint32_t *row, uint64_t tiles, uint32_t *s_wave) {
-  uint32_t carry = 0;
-  for (uint64_t base = 0; base < tiles; base += SCAN_BLOCK) {
-    const uint64_t k = base + threadIdx.x;
-    const uint32_t v = k < tiles ? row[k] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan(v, s_wave, &total);
-    if (k < tiles) row[k] = carry + ex;
-    carry += total;
-  }
-  return carry;
-}
 
 // One block per view (vk_gpu_draw_prefix, deferred.slang:354-377) plus one for
 // the transparent row.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
+  __shared__ uint4 s_wave4[SCAN_BLOCK / 64];
   __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
   const uint32_t v = blockIdx.x;
   if (v < a.views) {
-    uint32_t counts[4];
-    for (uint32_t b = 0; b < 4u; ++b)
-      counts[b] = scan_row(a.tile_counts + (uint64_t)(v * 4u + b) * a.tiles_stride, a.tiles, s_wave);
+    uint32_t *r0 = a.tile_counts + (uint64_t)(v * 4u + 0u) * a.tiles_stride;
+    uint32_t *r1 = a.tile_counts + (uint64_t)(v * 4u + 1u) * a.tiles_stride;
+    uint32_t *r2 = a.tile_counts + (uint64_t)(v * 4u + 2u) * a.tiles_stride;
+    uint32_t *r3 = a.tile_counts + (uint64_t)(v * 4u + 3u) * a.tiles_stride;
+    uint4 carry = make_uint4(0, 0, 0, 0);
+    for (uint64_t base = 0; base < a.tiles; base += SCAN_BLOCK) {
+      const uint64_t k = base + threadIdx.x;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (k < a.tiles) val = make_uint4(r0[k], r1[k], r2[k], r3[k]);
+      uint4 total;
+      const uint4 ex = block_exclusive_scan4(val, s_wave4, &total);
+      if (k < a.tiles) {
+        r0[k] = carry.x + ex.x;
+        r1[k] = carry.y + ex.y;
+        r2[k] = carry.z + ex.z;
+        r3[k] = carry.w + ex.w;
+      }
+      carry.x += total.x;
+      carry.y += total.y;
+      carry.z += total.z;
+      carry.w += total.w;
+    }
     if (threadIdx.x == 0) {
+      const uint32_t counts[4] = {carry.x, carry.y, carry.z, carry.w};
       CompactionState st;
       uint32_t cursor = 0, overflow = 0;
       const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
@@ -355,12 +448,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
       a.states[v] = st;
     }
   } else {
-    const uint32_t total =
-        scan_row(a.tile_counts + (uint64_t)(a.views * 4u) * a.tiles_stride, a.tiles, s_wave);
+    uint32_t *row = a.tile_counts + (uint64_t)(a.views * 4u) * a.tiles_stride;
+    uint32_t carry = 0;
+    for (uint64_t base = 0; base < a.tiles; base += SCAN_BLOCK) {
+      const uint64_t k = base + threadIdx.x;
+      const uint32_t val = k < a.tiles ? row[k] : 0u;
+      uint32_t total;
+      const uint32_t ex = block_exclusive_scan(val, s_wave, &total);
+      if (k < a.tiles) row[k] = carry + ex;
+      carry += total;
+    }
     if (threadIdx.x == 0) {
       const uint64_t cap = a.transparent_capacity;
-      a.counters[CNT_TRANSPARENT_TOTAL] = total;
-      a.counters[CNT_TRANSPARENT] = (uint64_t)total < cap ? total : (uint32_t)cap;
+      a.counters[CNT_TRANSPARENT_TOTAL] = carry;
+      a.counters[CNT_TRANSPARENT] = (uint64_t)carry < cap ? carry : (uint32_t)cap;
+      // lets the host pick the sort path of later frames without waiting
+      if (a.host_hint) *reinterpret_cast<volatile uint32_t *>(a.host_hint) = carry + 1u;
     }
   }
 }
@@ -369,10 +472,11 @@ struct ScatterArgs {
   const uint32_t *masks;
   const uint32_t *cflags;
   const uint8_t *tvis;
+  const uint64_t *tkey;
   const uint32_t *tile_offsets;  // scanned tile counts
   const CompactionState *states;
   uint32_t *visible;  // [view][visible_stride]
-  uint32_t *tlist;    // compacted visible blend rows (local candidate indices)
+  uint64_t *keys;     // compacted sort keys of the visible blend rows
   uint64_t n;
   uint64_t mask_stride;
   uint64_t tiles_stride;
@@ -401,23 +505,34 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
   const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
   const uint32_t words = (a.views + 31u) >> 5;
 
+  // all four rounds' inputs are requested up front
+  uint32_t cf_r[CULL_ROUNDS];
+  bool tv_r[CULL_ROUNDS];
+  uint32_t bits0_r[CULL_ROUNDS];
+#pragma unroll
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
+    const bool valid = i < a.n;
+    cf_r[round] = valid ? a.cflags[i] : 0xf0u;
+    tv_r[round] = valid ? a.tvis[i] != 0 : false;
+    bits0_r[round] = valid ? a.masks[i] : 0u;
+  }
+
+#pragma unroll
   for (int round = 0; round < CULL_ROUNDS; ++round) {
     const uint64_t base = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK;
     if (base >= a.n) break;
     const uint64_t i = base + t;
     const bool valid = i < a.n;
-    uint32_t cf = 0xf0u;
-    bool tv = false;
-    if (valid) {
-      cf = a.cflags[i];
-      tv = a.tvis[i] != 0;
-    }
+    const uint32_t cf = cf_r[round];
+    const bool tv = tv_r[round];
     const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
 
     // phase 1: per-wave survivor counts per row
     __syncthreads();  // s_wcnt readers of the previous round are done; s_base visible
     for (uint32_t w = 0; w < words; ++w) {
-      const uint32_t bits = valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u;
+      const uint32_t bits =
+          w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
       const uint32_t vend = min(a.views, (w + 1u) * 32u);
       for (uint32_t v = w * 32u; v < vend; ++v) {
         const bool pass = (bits >> (v & 31u)) & 1u;
@@ -436,7 +551,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
 
     // phase 2: positions
     for (uint32_t w = 0; w < words; ++w) {
-      const uint32_t bits = valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u;
+      const uint32_t bits =
+          w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
       const uint32_t vend = min(a.views, (w + 1u) * 32u);
       for (uint32_t v = w * 32u; v < vend; ++v) {
         const bool pass = (bits >> (v & 31u)) & 1u;
@@ -465,7 +581,9 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
       if (tv) {
         uint64_t pos = (uint64_t)s_base[row] + (uint32_t)__popcll(mt & lt_mask);
         for (uint32_t k = 0; k < wave; ++k) pos += s_wcnt[k][row];
-        if (pos < a.transparent_capacity) a.tlist[pos] = (uint32_t)i;
+        if (pos < a.transparent_capacity) {
+          a.keys[pos] = a.tkey[i];
+        }
       }
     }
     __syncthreads();

@@ -1,10 +1,12 @@
-// k_sort.hpp - transparent draw keys, stable LSD radix sort in LDS, draw emission.
+// k_sort.hpp - stable LSD radix sort of the transparent draw keys in LDS, and
+// draw emission.
 //
 // Key: ((uint64)bits(depth) << 32) | (source_index + 1), depth clamped >= 0
 // (lib/src/application.h:573-587), ordered DESCENDING by the reference's
 // comparator (lib/src/renderer/vkr_visibility.c:5-13) and qsort
 // (application.h:940-942). Keys are unique, so any correct sort reproduces the
-// reference's order.
+// reference's order. The low word names the source row, so no payload travels
+// with the key.
 //
 // The visible blend rows arrive in ascending source index. A STABLE ascending
 // sort on key bits [begin_bit, 64) followed by reading the result backwards
@@ -13,10 +15,14 @@
 // depth bits have to be moved through the radix passes. A full 64-bit sort
 // (begin_bit = 0) is the same code with eight passes.
 //
-// Per 8-bit pass: per-tile digit histogram -> exclusive scan over
-// (digit, tile) -> stable scatter with wave-ballot ranking (64-wide match on
-// the digit, per-wave digit counters in LDS). The element count lives in
-// device memory, so no host round trip sits between cull and sort.
+// Two paths, selected on the device from the element count (no host round
+// trip between cull and sort):
+//   count <= SMALL_KEYS  one workgroup keeps both key buffers in LDS and runs
+//                        every pass there (k_sort_small);
+//   larger               per 8-bit pass: per-tile digit histogram -> exclusive
+//                        scan over (digit, tile) -> stable scatter.
+// Ranking inside a wave is a 64-wide match on the digit built from eight
+// ballots, with per-wave running digit counters in LDS.
 #pragma once
 #include "device_math.hpp"
 #include "k_cull.hpp"
@@ -24,66 +30,203 @@
 namespace vkr {
 
 constexpr int SORT_BLOCK = 256;
-constexpr int SORT_ITEMS = 8;                          // keys per lane
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;     // 2048 keys per block
-constexpr int SORT_WAVE_KEYS = 64 * SORT_ITEMS;        // 512 consecutive keys per wave
+constexpr int SORT_ITEMS = 8;                       // keys per lane
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // 2048 keys per block
+constexpr int SORT_WAVE_KEYS = 64 * SORT_ITEMS;     // 512 consecutive keys per wave
 constexpr int SORT_RADIX = 256;
 
-struct KeygenArgs {
-  const uint32_t *tlist;     // visible blend rows, ascending local candidate index
-  const uint32_t *counters;  // CNT_TRANSPARENT
-  const float4 *world;
-  const uint32_t *node;
-  const float4 *sphere;
-  const float4 *view;  // camera view matrix columns
-  uint64_t *keys;
-  uint32_t *vals;
-  uint64_t index_base;
-};
+constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_WAVES = SMALL_THREADS / 64;
+constexpr int SMALL_KEYS = 8192;
+constexpr int SMALL_STEPS = SMALL_KEYS / SMALL_THREADS;  // 64-key steps per wave
+constexpr int SMALL_CHUNK = 4;                           // steps ranked together
 
-// application_transparent_depth + application_pack_transparent_sort_key,
-// application.h:573-587
-__global__ __launch_bounds__(256) void k_keygen(KeygenArgs a) {
-  const uint32_t count = a.counters[CNT_TRANSPARENT];
-  const uint32_t stride = gridDim.x * 256u;
-  Mat4 view;
-  view.c[0] = a.view[0];
-  view.c[1] = a.view[1];
-  view.c[2] = a.view[2];
-  view.c[3] = a.view[3];
-  for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < count; k += stride) {
-    const uint32_t i = a.tlist[k];
-    const uint64_t nd = a.node ? a.node[i] : i;
-    Mat4 m;
-    m.c[0] = a.world[nd * 4u + 0];
-    m.c[1] = a.world[nd * 4u + 1];
-    m.c[2] = a.world[nd * 4u + 2];
-    m.c[3] = a.world[nd * 4u + 3];
-    const float4 ls = a.sphere[i];
-    const float3 wc = mat4_mul_point(m, ls.x, ls.y, ls.z);
-    const float vz = mat4_mul_vec4_z(view, wc.x, wc.y, wc.z, 1.0f);
-    float depth = -vz;
-    depth = depth > 0.0f ? depth : 0.0f;
-    const uint32_t tie = (uint32_t)(a.index_base + i) + 1u;
-    a.keys[k] = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)tie;
-    a.vals[k] = i;
+// Lanes of the wave whose `digit` equals this lane's (restricted to `valid` lanes).
+__device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool valid) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (digit >> b) & 1u;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
   }
+  return peers;
+}
+
+// Stable ranks of one wave's keys for one digit position. The wave owns `STEPS`
+// groups of 64 consecutive keys (key[k] of lane l is element k*64 + l); on
+// return rank[k] is the number of the wave's keys with the same digit that come
+// before it, and whist[d] has grown by the wave's count of digit d. whist must
+// only be touched by this wave while this runs.
+//
+// The running per-digit count is kept by LDS atomics issued by the first lane of
+// every group of equal digits. They return in issue order and nothing consumes
+// their results until every step has issued, so the LDS latency is paid once
+// per tile, not once per step.
+template <int STEPS>
+__device__ __forceinline__ void wave_rank(const uint64_t (&key)[STEPS], const bool (&valid)[STEPS],
+                                          uint32_t steps, uint32_t shift, uint32_t *whist,
+                                          uint32_t (&rank)[STEPS]) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint32_t before[STEPS];
+  uint32_t leader[STEPS];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    before[k] = 0u;
+    leader[k] = 0u;
+    rank[k] = 0u;
+    if ((uint32_t)k < steps) {  // wave-uniform
+      const uint32_t digit = (uint32_t)(key[k] >> shift) & 0xffu;
+      const unsigned long long peers = match_digit(digit, valid[k]);
+      const unsigned long long lower = peers & lt_mask;
+      rank[k] = (uint32_t)__popcll(lower);
+      leader[k] = peers ? (uint32_t)__ffsll((long long)peers) - 1u : 0u;
+      if (valid[k] && lower == 0ull) before[k] = atomicAdd(&whist[digit], (uint32_t)__popcll(peers));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k)
+    if ((uint32_t)k < steps) rank[k] += (uint32_t)__shfl((int)before[k], (int)leader[k], 64);
 }
 
 struct SortArgs {
   const uint64_t *keys_in;
-  const uint32_t *vals_in;
   uint64_t *keys_out;
-  uint32_t *vals_out;
   uint32_t *hist;            // [digit][tiles_stride]
   const uint32_t *counters;  // CNT_TRANSPARENT
   uint32_t tiles_stride;
   uint32_t shift;
 };
 
+// LDS of the single-workgroup sort.
+struct SmallSortShared {
+  uint64_t keys[2][SMALL_KEYS];
+  uint16_t rank[SMALL_KEYS];  // rank of each key of the current tile inside its wave's digit run
+  uint32_t whist[SMALL_WAVES][SORT_RADIX];
+  uint32_t base[SORT_RADIX];
+  uint32_t wave[SMALL_THREADS / 64];
+  uint32_t skip;
+};
+
+// One stable pass of a whole array by ONE workgroup: digit histogram ->
+// exclusive scan -> tiles of SMALL_KEYS keys in order, each ranked by wave_rank
+// and scattered at (running digit base + wave prefix + rank). Returns false
+// (and writes nothing) when every key has the same digit. src/dst may be LDS or
+// global memory.
+__device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *dst,
+                                                 uint32_t count, uint32_t shift,
+                                                 SmallSortShared &s) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t wave = t >> 6;
+  const uint32_t lane = t & 63u;
+  __syncthreads();  // src is complete, the previous pass is done with s
+  if (t < SORT_RADIX) s.base[t] = 0u;
+  if (t == 0) s.skip = 0u;
+  __syncthreads();
+  for (uint32_t idx = t; idx < count; idx += SMALL_THREADS)
+    atomicAdd(&s.base[(uint32_t)(src[idx] >> shift) & 0xffu], 1u);
+  __syncthreads();
+  const uint32_t tot = t < SORT_RADIX ? s.base[t] : 0u;
+  if (t < SORT_RADIX && tot == count) s.skip = 1u;
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan(tot, s.wave, &total);
+  __syncthreads();
+  if (t < SORT_RADIX) s.base[t] = ex;
+  if (s.skip) return false;  // uniform: read after the barrier above
+
+  for (uint32_t tile_base = 0; tile_base < count; tile_base += SMALL_KEYS) {
+    __syncthreads();  // s.base updated, previous tile's whist readers done
+    for (uint32_t d = t; d < SMALL_WAVES * SORT_RADIX; d += SMALL_THREADS) (&s.whist[0][0])[d] = 0u;
+    __syncthreads();
+    const uint32_t n_tile = min((uint32_t)SMALL_KEYS, count - tile_base);
+    const uint32_t steps = (n_tile + SMALL_THREADS - 1) / SMALL_THREADS;  // per wave, <= SMALL_STEPS
+    const uint32_t wbase = tile_base + wave * steps * 64u;
+    const uint32_t tile_end = tile_base + n_tile;
+    // ranks, four steps at a time (keeps the register footprint small; the ranks
+    // wait in LDS for the scatter)
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < steps; k0 += SMALL_CHUNK) {
+      uint64_t key[SMALL_CHUNK];
+      bool valid[SMALL_CHUNK];
+      uint32_t rank[SMALL_CHUNK];
+#pragma unroll
+      for (int k = 0; k < SMALL_CHUNK; ++k) {
+        const uint32_t idx = wbase + (k0 + (uint32_t)k) * 64u + lane;
+        valid[k] = k0 + (uint32_t)k < steps && idx < tile_end;
+        key[k] = valid[k] ? src[idx] : 0ull;
+      }
+      wave_rank<SMALL_CHUNK>(key, valid, steps - k0, shift, s.whist[wave], rank);
+#pragma unroll
+      for (int k = 0; k < SMALL_CHUNK; ++k) {
+        const uint32_t idx = wbase + (k0 + (uint32_t)k) * 64u + lane;
+        if (valid[k]) s.rank[idx - tile_base] = (uint16_t)rank[k];
+      }
+    }
+    __syncthreads();
+    if (t < SORT_RADIX) {
+      uint32_t run = s.base[t];
+#pragma unroll
+      for (int w = 0; w < SMALL_WAVES; ++w) {
+        const uint32_t c = s.whist[w][t];
+        s.whist[w][t] = run;
+        run += c;
+      }
+      s.base[t] = run;  // running base of the next tile
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t k = 0; k < steps; ++k) {
+      const uint32_t idx = wbase + k * 64u + lane;
+      if (idx < tile_end) {
+        const uint64_t key = src[idx];
+        const uint32_t digit = (uint32_t)(key >> shift) & 0xffu;
+        dst[s.whist[wave][digit] + s.rank[idx - tile_base]] = key;
+      }
+    }
+  }
+  return true;
+}
+
+// Sort of keys[0, count) on bits [begin_shift, 64) by one workgroup, result in
+// `keys`. count <= SMALL_KEYS runs entirely in LDS. Larger counts are sorted
+// only when `any_count` is set (the host launched no multi-pass kernels because
+// it expected a small count): the same passes then stream through global memory
+// between `keys` and `scratch` - correct, but at one CU's bandwidth.
+__global__ __launch_bounds__(SMALL_THREADS) void k_sort_small(uint64_t *keys, uint64_t *scratch,
+                                                              const uint32_t *counters,
+                                                              uint32_t begin_shift,
+                                                              uint32_t any_count) {
+  __shared__ SmallSortShared s;
+  const uint32_t count = counters[CNT_TRANSPARENT];
+  if (count == 0) return;
+  const uint32_t t = threadIdx.x;
+  if (count <= SMALL_KEYS) {
+    for (uint32_t k = t; k < count; k += SMALL_THREADS) s.keys[0][k] = keys[k];
+    uint32_t cur = 0;
+    for (uint32_t shift = begin_shift; shift < 64u; shift += 8u)
+      if (block_radix_pass(s.keys[cur], s.keys[cur ^ 1u], count, shift, s)) cur ^= 1u;
+    __syncthreads();
+    for (uint32_t k = t; k < count; k += SMALL_THREADS) keys[k] = s.keys[cur][k];
+  } else if (any_count) {
+    uint64_t *src = keys, *dst = scratch;
+    for (uint32_t shift = begin_shift; shift < 64u; shift += 8u) {
+      if (block_radix_pass(src, dst, count, shift, s)) {
+        uint64_t *tmp = src;
+        src = dst;
+        dst = tmp;
+      }
+    }
+    __syncthreads();
+    if (src != keys)
+      for (uint32_t k = t; k < count; k += SMALL_THREADS) keys[k] = src[k];
+  }
+}
+
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
   __shared__ uint32_t s_hist[SORT_RADIX];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
+  if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -105,8 +248,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
 __global__ __launch_bounds__(SCAN_BLOCK) void k_radix_scan(SortArgs a) {
   __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
+  if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
-  if (tiles == 0) return;
   const uint64_t total_entries = (uint64_t)SORT_RADIX * tiles;
   uint32_t carry = 0;
   for (uint64_t base = 0; base < total_entries; base += SCAN_BLOCK) {
@@ -130,15 +273,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_radix_scan(SortArgs a) {
 // and walks them in 8 steps of 64 consecutive keys, so (wave, step, lane) order
 // is memory order.
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
-  __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave running digit counts
+  __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave digit counts, then bases
   __shared__ uint32_t s_base[SORT_RADIX];      // global base of (digit, tile)
   const uint32_t count = a.counters[CNT_TRANSPARENT];
+  if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
   const uint32_t wave = t >> 6;
   const uint32_t lane = t & 63u;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  volatile uint32_t *whist = s_whist[wave];
 
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     __syncthreads();  // previous tile's readers are done
@@ -147,35 +289,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
     __syncthreads();
 
     uint64_t key[SORT_ITEMS];
-    uint32_t val[SORT_ITEMS];
+    bool valid[SORT_ITEMS];
     uint32_t rank[SORT_ITEMS];
     const uint32_t wbase = tile * SORT_TILE + wave * SORT_WAVE_KEYS;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
       const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
-      const bool valid = idx < count;
-      key[k] = valid ? a.keys_in[idx] : 0ull;
-      val[k] = valid ? a.vals_in[idx] : 0u;
+      valid[k] = idx < count;
+      key[k] = valid[k] ? a.keys_in[idx] : 0ull;
     }
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-      const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
-      const bool valid = idx < count;
-      const uint32_t digit = (uint32_t)(key[k] >> a.shift) & 0xffu;
-      // lanes holding the same digit (invalid lanes match nobody)
-      unsigned long long peers = __ballot(valid);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const bool bit = (digit >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
-      const uint32_t before = whist[digit];
-      rank[k] = before + (uint32_t)__popcll(peers & lt_mask);
-      __builtin_amdgcn_wave_barrier();
-      if (valid && (peers & lt_mask) == 0ull) whist[digit] = before + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-    }
+    wave_rank<SORT_ITEMS>(key, valid, SORT_ITEMS, a.shift, s_whist[wave], rank);
     __syncthreads();
     // exclusive prefix of the per-wave digit totals across waves, plus the
     // global base of this tile's digit run
@@ -191,12 +314,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
-      const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
-      if (idx < count) {
+      if (valid[k]) {
         const uint32_t digit = (uint32_t)(key[k] >> a.shift) & 0xffu;
-        const uint32_t pos = s_whist[wave][digit] + rank[k];
-        a.keys_out[pos] = key[k];
-        a.vals_out[pos] = val[k];
+        a.keys_out[s_whist[wave][digit] + rank[k]] = key[k];
       }
     }
   }
@@ -204,7 +324,6 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
 
 struct EmitArgs {
   const uint64_t *keys;      // ascending-sorted
-  const uint32_t *vals;      // local candidate index per key
   const uint32_t *counters;  // CNT_TRANSPARENT
   const float4 *world;
   const uint32_t *node;
@@ -213,6 +332,7 @@ struct EmitArgs {
   float4 *instances;   // 5 x float4 per row: VkrInstanceDataGPU
   uint64_t *out_keys;  // descending
   uint32_t *out_source;
+  uint64_t index_base;
 };
 
 // vkr_picking_encode_id(SCENE, render_id), systems/vkr_picking_ids.h:35-42;
@@ -235,7 +355,8 @@ __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
        row += gridDim.x * rows_per_block) {
     const uint32_t slot = count - 1u - row;  // read the ascending result backwards
     const uint64_t key = a.keys[slot];
-    const uint32_t i = a.vals[slot];
+    // the low word is source_index + 1 (application.h:657-658)
+    const uint32_t i = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
     if (piece < 3u) {
       uint4 o;
       if (piece == 0u) {
@@ -275,8 +396,8 @@ struct CandidateEmitArgs {
 };
 
 // application_emit_world_source, application.h:617-641: one 144-byte
-// VkrWorldDrawCandidate per source row; 9 sixteen-byte pieces written by 9 of
-// every 16 lanes... kept simple: 16 lanes per row, pieces 0-8 active.
+// VkrWorldDrawCandidate per source row, written as nine 16-byte pieces by nine
+// of every sixteen lanes.
 __global__ __launch_bounds__(256) void k_emit_candidates(CandidateEmitArgs a) {
   const uint64_t row = (uint64_t)blockIdx.x * 16u + (threadIdx.x >> 4);
   const uint32_t piece = threadIdx.x & 15u;

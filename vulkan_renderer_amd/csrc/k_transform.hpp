@@ -25,6 +25,8 @@ constexpr uint8_t F_DIRTY_LOCAL = 0x01;
 constexpr uint8_t F_DIRTY_WORLD = 0x02;
 constexpr uint8_t F_WORLD_UPDATED = 0x08;
 constexpr uint32_t NO_PARENT = 0xffffffffu;
+constexpr uint32_t TF_STAT_SHARDS = 64;  // = STAT_SHARDS
+constexpr uint32_t TF_CNT_STRIDE = 8;    // = CNT_COUNT; slot 0 = CNT_NODES_UPDATED
 
 struct TransformArgs {
   const uint32_t *parent;  // global array, indexed by node
@@ -34,7 +36,7 @@ struct TransformArgs {
   float4 *local;  // 4 float4 per node
   float4 *world;
   uint8_t *flags;
-  uint32_t *nodes_updated;
+  uint32_t *counters;  // sharded frame counters; blocks add to NODES_UPDATED of their shard
   uint64_t begin;  // level range [begin, end)
   uint64_t end;
   uint32_t force;  // flag bits OR-ed into every node first (bulk "everything moved")
@@ -80,69 +82,87 @@ __global__ __launch_bounds__(TF_BLOCK) void k_propagate_level(TransformArgs a) {
     __syncthreads();
   }
 
+  // The four sub-rounds are written as separate passes so that every load of
+  // the tile is in flight before the first result is consumed.
   const uint32_t col = t & 3u;
-  uint32_t updated_here = 0;
+  uint8_t f[4];
+  bool valid[4];
+  uint32_t par[4];
+  float4 lcol[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
     const uint64_t node = tile_base + slot;
-    const bool valid = node < a.end;
-    bool did_update = false;
-    if (valid) {
-      uint8_t f = (uint8_t)(a.flags[node] | a.force);
-      // pass 1, vkr_scene_system.c:592-603
-      f &= (uint8_t)~F_WORLD_UPDATED;
-      float4 lcol;
-      bool have_local = false;
-      if (f & F_DIRTY_LOCAL) {
-        if (a.pos != nullptr) {
-          lcol = local_col_from_trs(a.pos[node], a.quat[node], a.scale[node], col);
-          have_local = true;
-          a.local[node * 4u + col] = lcol;
-        }
-        f = (uint8_t)((f & ~F_DIRTY_LOCAL) | F_DIRTY_WORLD);
-      }
-      // pass 2, vkr_scene_system.c:1304-1336
-      uint32_t p = NO_PARENT;
-      if (HAS_PARENT) {
-        p = s_par[slot];
-        if (p != NO_PARENT) {
-          const uint8_t pf = window ? s_pflags[p - pmin] : a.flags[p];
-          if (pf & F_WORLD_UPDATED) f |= F_DIRTY_WORLD;
-        }
-      }
-      if (f & F_DIRTY_WORLD) {
-        if (!have_local) lcol = a.local[node * 4u + col];
-        float4 wcol = lcol;
-        if (HAS_PARENT && p != NO_PARENT) {
-          float4 a0, a1, a2, a3;
-          if (window) {
-            const float4 *pw = s_pworld + (p - pmin) * 4u;
-            a0 = pw[0];
-            a1 = pw[1];
-            a2 = pw[2];
-            a3 = pw[3];
-          } else {
-            const float4 *pw = a.world + (uint64_t)p * 4u;
-            a0 = pw[0];
-            a1 = pw[1];
-            a2 = pw[2];
-            a3 = pw[3];
-          }
-          wcol = mat4_mul_col(a0, a1, a2, a3, lcol);
-        }
-        a.world[node * 4u + col] = wcol;
-        f = (uint8_t)((f & ~F_DIRTY_WORLD) | F_WORLD_UPDATED);
-        did_update = true;
-      }
-      if (col == 0) a.flags[node] = f;
+    valid[r] = node < a.end;
+    f[r] = valid[r] ? (uint8_t)(a.flags[node] | a.force) : (uint8_t)0;
+    par[r] = NO_PARENT;
+    if (HAS_PARENT) par[r] = s_par[slot];
+  }
+  // pass 1 flag handling (vkr_scene_system.c:592-603) and the parent-updated
+  // test of pass 2 (:1310-1316)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f[r] &= (uint8_t)~F_WORLD_UPDATED;
+    if (HAS_PARENT && valid[r] && par[r] != NO_PARENT) {
+      const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.flags[par[r]];
+      if (pf & F_WORLD_UPDATED) f[r] |= F_DIRTY_WORLD;
     }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t node = tile_base + (uint32_t)r * 64u + (t >> 2);
+    lcol[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid[r]) {
+      if (f[r] & F_DIRTY_LOCAL) {
+        if (a.pos != nullptr) {
+          lcol[r] = local_col_from_trs(a.pos[node], a.quat[node], a.scale[node], col);
+          a.local[node * 4u + col] = lcol[r];
+        } else {
+          lcol[r] = a.local[node * 4u + col];
+        }
+        f[r] = (uint8_t)((f[r] & ~F_DIRTY_LOCAL) | F_DIRTY_WORLD);
+      } else if (f[r] & F_DIRTY_WORLD) {
+        lcol[r] = a.local[node * 4u + col];
+      }
+    }
+  }
+  // pass 2 proper, vkr_scene_system.c:1319-1336
+  uint32_t updated_here = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t node = tile_base + (uint32_t)r * 64u + (t >> 2);
+    bool did_update = false;
+    if (valid[r] && (f[r] & F_DIRTY_WORLD)) {
+      float4 wcol = lcol[r];
+      if (HAS_PARENT && par[r] != NO_PARENT) {
+        float4 a0, a1, a2, a3;
+        if (window) {
+          const float4 *pw = s_pworld + (par[r] - pmin) * 4u;
+          a0 = pw[0];
+          a1 = pw[1];
+          a2 = pw[2];
+          a3 = pw[3];
+        } else {
+          const float4 *pw = a.world + (uint64_t)par[r] * 4u;
+          a0 = pw[0];
+          a1 = pw[1];
+          a2 = pw[2];
+          a3 = pw[3];
+        }
+        wcol = mat4_mul_col(a0, a1, a2, a3, lcol[r]);
+      }
+      a.world[node * 4u + col] = wcol;
+      f[r] = (uint8_t)((f[r] & ~F_DIRTY_WORLD) | F_WORLD_UPDATED);
+      did_update = true;
+    }
+    if (valid[r] && col == 0) a.flags[node] = f[r];
     const unsigned long long m = __ballot(did_update && col == 0);
     if ((t & 63u) == 0) updated_here += (uint32_t)__popcll(m);
   }
   if ((t & 63u) == 0 && updated_here) atomicAdd(&s_updated, updated_here);
   __syncthreads();
-  if (t == 0 && s_updated) atomicAdd(a.nodes_updated, s_updated);
+  if (t == 0 && s_updated)
+    atomicAdd(a.counters + (blockIdx.x % TF_STAT_SHARDS) * TF_CNT_STRIDE + 0u, s_updated);
 }
 
 // scene_compute_local_matrix over a node range, without touching flags or

@@ -16,6 +16,7 @@
 
 #include "device_math.hpp"
 #include "k_cull.hpp"
+#include "k_fused.hpp"
 #include "k_sort.hpp"
 #include "k_transform.hpp"
 
@@ -79,24 +80,35 @@ struct vkrhip_ctx {
   uint64_t tiles_stride = 0;
   DevBuf<uint32_t> masks;
   DevBuf<uint8_t> tvis;
-  DevBuf<uint32_t> tile_counts;
   DevBuf<CompactionState> states;
-  DevBuf<uint32_t> counters;
-  DevBuf<unsigned long long> ties;
+  // zeroed by one fill per frame: [counters | tie counters | tile counts]
+  DevBuf<uint8_t> frame_zero;
+  static constexpr size_t kCountersBytes = sizeof(uint32_t) * CNT_COUNT * STAT_SHARDS;
+  static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
+  size_t zero_header_bytes() const { return kCountersBytes + kTiesBytes; }
+  uint32_t *counters() const { return reinterpret_cast<uint32_t *>(frame_zero.p); }
+  unsigned long long *ties() const {
+    return reinterpret_cast<unsigned long long *>(frame_zero.p + kCountersBytes);
+  }
+  uint32_t *tile_counts() const {
+    return reinterpret_cast<uint32_t *>(frame_zero.p + kCountersBytes + kTiesBytes);
+  }
+  DevBuf<uint64_t> tkey;
   DevBuf<uint32_t> visible;
   uint64_t visible_stride = 0;
   DevBuf<float4> world_bounds;
   DevBuf<uint4> cand_rows;
 
   // transparent
-  DevBuf<uint32_t> tlist;
   DevBuf<uint64_t> keys_a, keys_b, out_keys;
-  DevBuf<uint32_t> vals_a, vals_b, out_source;
+  DevBuf<uint32_t> out_source;
   DevBuf<uint32_t> hist;
   uint32_t sort_tiles_stride = 0;
   DevBuf<uint4> draws;
   DevBuf<float4> instances;
-  bool sorted_in_a = true;
+
+  // pinned host word the scan kernel writes (transparent count + 1; 0 = unknown)
+  uint32_t *host_hint = nullptr;
 
   // merge scratch
   DevBuf<const uint64_t *> merge_ptrs;
@@ -271,13 +283,15 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     c->tiles_stride = ceil_div(mc, CULL_TILE);
     TRY(dev_alloc(c, c->masks, (size_t)c->mask_words * mc));
     TRY(dev_alloc(c, c->tvis, mc));
-    TRY(dev_alloc(c, c->tile_counts, (size_t)(c->cfg.max_views * 4u + 1u) * c->tiles_stride));
+    TRY(dev_alloc(c, c->frame_zero,
+                  c->zero_header_bytes() +
+                      (size_t)(c->cfg.max_views * 4u + 1u) * c->tiles_stride * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, c->frame_zero.count, c->stream));
+    TRY(dev_alloc(c, c->tkey, mc));
     TRY(dev_alloc(c, c->states, VKRHIP_MAX_VIEWS));
-    TRY(dev_alloc(c, c->counters, CNT_COUNT));
-    TRY(dev_alloc(c, c->ties, VKRHIP_MAX_VIEWS));
     HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * CNT_COUNT, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->ties.p, 0, sizeof(unsigned long long) * VKRHIP_MAX_VIEWS, c->stream));
+    HIP_TRY(c, hipHostMalloc((void **)&c->host_hint, 64, hipHostMallocMapped));
+    c->host_hint[0] = 0u;
     c->visible_stride = c->cfg.visible_capacity;
     TRY(dev_alloc(c, c->visible, (size_t)c->cfg.max_views * c->visible_stride));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -322,19 +336,15 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->camera_view);
   dev_free(c->masks);
   dev_free(c->tvis);
-  dev_free(c->tile_counts);
+  dev_free(c->frame_zero);
+  dev_free(c->tkey);
   dev_free(c->states);
-  dev_free(c->counters);
-  dev_free(c->ties);
   dev_free(c->visible);
   dev_free(c->world_bounds);
   dev_free(c->cand_rows);
-  dev_free(c->tlist);
   dev_free(c->keys_a);
   dev_free(c->keys_b);
   dev_free(c->out_keys);
-  dev_free(c->vals_a);
-  dev_free(c->vals_b);
   dev_free(c->out_source);
   dev_free(c->hist);
   dev_free(c->draws);
@@ -342,6 +352,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->merge_ptrs);
   dev_free(c->merge_lens);
   dev_free(c->concat_desc);
+  if (c->host_hint) (void)hipHostFree(c->host_hint);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -529,13 +540,10 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
   }
   // transparent buffers sized by the rows that can ever enter the blend list
   const uint64_t tcap = std::max<uint64_t>(1, std::min<uint64_t>(blend, c->cfg.transparent_capacity));
-  if (tcap > c->tcap || !c->tlist.p) {
-    TRY(dev_alloc(c, c->tlist, tcap));
+  if (tcap > c->tcap || !c->keys_a.p) {
     TRY(dev_alloc(c, c->keys_a, tcap));
     TRY(dev_alloc(c, c->keys_b, tcap));
     TRY(dev_alloc(c, c->out_keys, tcap));
-    TRY(dev_alloc(c, c->vals_a, tcap));
-    TRY(dev_alloc(c, c->vals_b, tcap));
     TRY(dev_alloc(c, c->out_source, tcap));
     c->sort_tiles_stride = (uint32_t)ceil_div(tcap, SORT_TILE);
     TRY(dev_alloc(c, c->hist, (size_t)SORT_RADIX * c->sort_tiles_stride));
@@ -573,22 +581,52 @@ int vkrhip_set_views(vkrhip_ctx *c, uint32_t views, const float *planes,
 // ---------------------------------------------------------------------------
 // the frame
 // ---------------------------------------------------------------------------
+static TransformArgs transform_args(vkrhip_ctx *c, uint32_t level) {
+  TransformArgs a{};
+  a.parent = c->parent.p;
+  a.pos = c->have_trs ? c->pos.p : nullptr;
+  a.quat = c->quat.p;
+  a.scale = c->scale.p;
+  a.local = c->local.p;
+  a.world = c->world.p;
+  a.flags = c->flags.p;
+  a.counters = c->counters();
+  a.begin = c->level_offsets[level];
+  a.end = c->level_offsets[level + 1];
+  a.force = c->force_flags;
+  return a;
+}
+
+static CullArgs cull_args(vkrhip_ctx *c) {
+  CullArgs a{};
+  a.world = c->world.p;
+  a.node = c->node_identity ? nullptr : c->node.p;
+  a.sphere = c->sphere.p;
+  a.cflags = c->cflags.p;
+  a.planes = c->planes.p;
+  a.tie_eps = c->tie_eps.p;
+  a.required = c->required.p;
+  a.view = c->camera_view.p;
+  a.masks = c->masks.p;
+  a.tvis = c->tvis.p;
+  a.tkey = c->tkey.p;
+  a.world_bounds = c->world_bounds.p;
+  a.tile_counts = c->tile_counts();
+  a.counters = c->counters();
+  a.ties = c->ties();
+  a.n = c->n_cand;
+  a.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
+  a.tiles_stride = c->tiles_stride;
+  a.index_base = c->cfg.source_index_base;
+  a.views = c->views;
+  return a;
+}
+
 static int launch_transform(vkrhip_ctx *c) {
   StageTimer timer(c, VKRHIP_TIMER_TRANSFORM);
   const uint32_t levels = c->level_offsets.empty() ? 0u : (uint32_t)c->level_offsets.size() - 1u;
   for (uint32_t l = 0; l < levels; ++l) {
-    TransformArgs a{};
-    a.parent = c->parent.p;
-    a.pos = c->have_trs ? c->pos.p : nullptr;
-    a.quat = c->quat.p;
-    a.scale = c->scale.p;
-    a.local = c->local.p;
-    a.world = c->world.p;
-    a.flags = c->flags.p;
-    a.nodes_updated = c->counters.p + CNT_NODES_UPDATED;
-    a.begin = c->level_offsets[l];
-    a.end = c->level_offsets[l + 1];
-    a.force = c->force_flags;
+    const TransformArgs a = transform_args(c, l);
     if (a.end == a.begin) continue;
     const unsigned grid = (unsigned)ceil_div(a.end - a.begin, TF_TILE);
     if (l == 0 || !c->parent.p)
@@ -601,65 +639,92 @@ static int launch_transform(vkrhip_ctx *c) {
   return VKRHIP_OK;
 }
 
-template <bool IDENTITY>
-static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned grid, bool ties,
-                                    bool bounds_out) {
+template <bool HAS_PARENT>
+static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
+                                 bool bounds_out) {
+  const dim3 g(grid), b(FUSED_BLOCK);
   if (ties) {
     if (bounds_out)
-      hipLaunchKernelGGL((k_classify<IDENTITY, true, true>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, true>), g, b, 0, c->stream, a);
     else
-      hipLaunchKernelGGL((k_classify<IDENTITY, true, false>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, false>), g, b, 0, c->stream, a);
   } else {
     if (bounds_out)
-      hipLaunchKernelGGL((k_classify<IDENTITY, false, true>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, true>), g, b, 0, c->stream, a);
     else
-      hipLaunchKernelGGL((k_classify<IDENTITY, false, false>), dim3(grid), dim3(CULL_BLOCK), 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, false>), g, b, 0, c->stream, a);
   }
 }
 
-static int launch_cull(vkrhip_ctx *c, bool bounds_out) {
+// Transform and classify in one launch per level (candidate i <-> node i).
+static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
+  StageTimer timer(c, VKRHIP_TIMER_FUSED);
+  const uint32_t levels = (uint32_t)c->level_offsets.size() - 1u;
+  const bool ties = c->cfg.tie_epsilon > 0.f;
+  for (uint32_t l = 0; l < levels; ++l) {
+    FusedArgs a{};
+    a.t = transform_args(c, l);
+    a.c = cull_args(c);
+    if (a.t.end == a.t.begin) continue;
+    const unsigned grid =
+        (unsigned)(ceil_div(a.t.end, FUSED_BLOCK) - a.t.begin / FUSED_BLOCK);
+    if (l == 0 || !c->parent.p)
+      launch_fused_variant<false>(c, a, grid, ties, bounds_out);
+    else
+      launch_fused_variant<true>(c, a, grid, ties, bounds_out);
+  }
+  c->force_flags = 0;
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+template <bool IDENTITY>
+static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned grid, bool ties,
+                                    bool bounds_out) {
+  const dim3 g(grid), b(CULL_BLOCK);
+  if (ties) {
+    if (bounds_out)
+      hipLaunchKernelGGL((k_classify<IDENTITY, true, true>), g, b, 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_classify<IDENTITY, true, false>), g, b, 0, c->stream, a);
+  } else {
+    if (bounds_out)
+      hipLaunchKernelGGL((k_classify<IDENTITY, false, true>), g, b, 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_classify<IDENTITY, false, false>), g, b, 0, c->stream, a);
+  }
+}
+
+static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
+  if (!c->n_cand) return VKRHIP_OK;
+  StageTimer timer(c, VKRHIP_TIMER_CLASSIFY);
+  const CullArgs a = cull_args(c);
+  const unsigned grid = (unsigned)ceil_div(c->n_cand, CULL_BLOCK);
+  const bool ties = c->cfg.tie_epsilon > 0.f;
+  if (c->node_identity)
+    launch_classify_variant<true>(c, a, grid, ties, bounds_out);
+  else
+    launch_classify_variant<false>(c, a, grid, ties, bounds_out);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+static int launch_compaction(vkrhip_ctx *c) {
   const uint64_t n = c->n_cand;
   const uint64_t tiles = ceil_div(n, CULL_TILE);
-  if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
-  if (tiles) {
-    StageTimer timer(c, VKRHIP_TIMER_CLASSIFY);
-    CullArgs a{};
-    a.world = c->world.p;
-    a.node = c->node_identity ? nullptr : c->node.p;
-    a.sphere = c->sphere.p;
-    a.cflags = c->cflags.p;
-    a.planes = c->planes.p;
-    a.tie_eps = c->tie_eps.p;
-    a.required = c->required.p;
-    a.masks = c->masks.p;
-    a.tvis = c->tvis.p;
-    a.world_bounds = c->world_bounds.p;
-    a.tile_counts = c->tile_counts.p;
-    a.counters = c->counters.p;
-    a.ties = c->ties.p;
-    a.n = n;
-    a.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
-    a.tiles_stride = c->tiles_stride;
-    a.views = c->views;
-    const bool ties = c->cfg.tie_epsilon > 0.f;
-    if (c->node_identity)
-      launch_classify_variant<true>(c, a, (unsigned)tiles, ties, bounds_out);
-    else
-      launch_classify_variant<false>(c, a, (unsigned)tiles, ties, bounds_out);
-    HIP_TRY(c, hipGetLastError());
-  }
   {
     StageTimer timer(c, VKRHIP_TIMER_SCAN);
     ScanArgs s{};
-    s.tile_counts = c->tile_counts.p;
+    s.tile_counts = c->tile_counts();
     s.states = c->states.p;
-    s.counters = c->counters.p;
+    s.counters = c->counters();
     s.tiles = tiles;
     s.tiles_stride = c->tiles_stride;
     s.views = c->views;
     s.partition_capacity = c->cfg.partition_capacity;
     s.visible_capacity = c->visible_stride;
     s.transparent_capacity = c->tcap;
+    s.host_hint = c->host_hint;
     hipLaunchKernelGGL(k_scan, dim3(c->views + 1u), dim3(SCAN_BLOCK), 0, c->stream, s);
     HIP_TRY(c, hipGetLastError());
   }
@@ -669,10 +734,11 @@ static int launch_cull(vkrhip_ctx *c, bool bounds_out) {
     s.masks = c->masks.p;
     s.cflags = c->cflags.p;
     s.tvis = c->tvis.p;
-    s.tile_offsets = c->tile_counts.p;
+    s.tkey = c->tkey.p;
+    s.tile_offsets = c->tile_counts();
     s.states = c->states.p;
     s.visible = c->visible.p;
-    s.tlist = c->tlist.p;
+    s.keys = c->keys_a.p;
     s.n = n;
     s.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
     s.tiles_stride = c->tiles_stride;
@@ -690,50 +756,45 @@ static int launch_cull(vkrhip_ctx *c, bool bounds_out) {
 static int launch_transparent(vkrhip_ctx *c) {
   const uint64_t cap = std::min<uint64_t>(c->tcap, std::max<uint64_t>(c->blend_rows, 1));
   {
-    StageTimer timer(c, VKRHIP_TIMER_KEYGEN);
-    KeygenArgs k{};
-    k.tlist = c->tlist.p;
-    k.counters = c->counters.p;
-    k.world = c->world.p;
-    k.node = c->node_identity ? nullptr : c->node.p;
-    k.sphere = c->sphere.p;
-    k.view = c->camera_view.p;
-    k.keys = c->keys_a.p;
-    k.vals = c->vals_a.p;
-    k.index_base = c->cfg.source_index_base;
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, 256), 2048);
-    hipLaunchKernelGGL(k_keygen, dim3(grid), dim3(256), 0, c->stream, k);
-    HIP_TRY(c, hipGetLastError());
-  }
-  bool in_a = true;
-  {
     StageTimer timer(c, VKRHIP_TIMER_SORT);
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
-    // depth bits only: the low word is already ordered by construction
-    for (uint32_t shift = 32; shift < 64; shift += 8) {
-      SortArgs s{};
-      s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
-      s.vals_in = in_a ? c->vals_a.p : c->vals_b.p;
-      s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
-      s.vals_out = in_a ? c->vals_b.p : c->vals_a.p;
-      s.hist = c->hist.p;
-      s.counters = c->counters.p;
-      s.tiles_stride = c->sort_tiles_stride;
-      s.shift = shift;
-      hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-      in_a = !in_a;
+    // Depth bits only: the low word is already ordered by construction. The
+    // element count is only known on the device. A single workgroup sorts
+    // count <= SMALL_KEYS in LDS; above that the multi-pass kernels do the work
+    // (and return at once below it). When the bound on the count is small, or
+    // the count the scan kernel reported for an earlier frame was comfortably
+    // small, the multi-pass kernels are not launched at all and the single
+    // workgroup is told to sort whatever it finds, so a wrong guess costs time,
+    // never correctness. After four passes the multi-pass result is back in
+    // keys_a too.
+    const uint32_t hint = *reinterpret_cast<volatile uint32_t *>(c->host_hint);
+    const bool expect_small =
+        cap <= SMALL_KEYS || (hint != 0u && (uint64_t)(hint - 1u) * 5u / 4u + 256u <= SMALL_KEYS);
+    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SMALL_THREADS), 0, c->stream, c->keys_a.p,
+                       c->keys_b.p, c->counters(), 32u, expect_small ? 1u : 0u);
+    if (!expect_small) {
+      const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
+      bool in_a = true;
+      for (uint32_t shift = 32; shift < 64; shift += 8) {
+        SortArgs s{};
+        s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
+        s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
+        s.hist = c->hist.p;
+        s.counters = c->counters();
+        s.tiles_stride = c->sort_tiles_stride;
+        s.shift = shift;
+        hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+        in_a = !in_a;
+      }
     }
     HIP_TRY(c, hipGetLastError());
   }
-  c->sorted_in_a = in_a;
   {
     StageTimer timer(c, VKRHIP_TIMER_EMIT);
     EmitArgs e{};
-    e.keys = in_a ? c->keys_a.p : c->keys_b.p;
-    e.vals = in_a ? c->vals_a.p : c->vals_b.p;
-    e.counters = c->counters.p;
+    e.keys = c->keys_a.p;
+    e.counters = c->counters();
     e.world = c->world.p;
     e.node = c->node_identity ? nullptr : c->node.p;
     e.ident = c->ident.p;
@@ -741,6 +802,7 @@ static int launch_transparent(vkrhip_ctx *c) {
     e.instances = c->instances.p;
     e.out_keys = c->out_keys.p;
     e.out_source = c->out_source.p;
+    e.index_base = c->cfg.source_index_base;
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, 32), 4096);
     hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, e);
     HIP_TRY(c, hipGetLastError());
@@ -780,13 +842,28 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
       c->n_cand > c->cfg.max_nodes)
     return fail(c, VKRHIP_ERR_STATE, "identity node mapping with more candidates than nodes");
   TRY(bind_device(c));
+  const bool cull = (stages & VKRHIP_STAGE_CULL) != 0;
+  const bool bounds_out = (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0;
+  if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
   {
     StageTimer frame_timer(c, VKRHIP_TIMER_FRAME);
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * CNT_COUNT, c->stream));
-    if (c->cfg.tie_epsilon > 0.f)
-      HIP_TRY(c, hipMemsetAsync(c->ties.p, 0, sizeof(unsigned long long) * VKRHIP_MAX_VIEWS, c->stream));
-    if (stages & VKRHIP_STAGE_TRANSFORM) TRY(launch_transform(c));
-    if (stages & VKRHIP_STAGE_CULL) TRY(launch_cull(c, (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0));
+    // one fill zeroes the counters, the tie counters and the tile counts in use
+    const uint64_t tiles = ceil_div(c->n_cand, CULL_TILE);
+    const size_t zero_bytes =
+        cull ? c->zero_header_bytes() +
+                   ((size_t)(c->views * 4u) * c->tiles_stride + tiles) * sizeof(uint32_t)
+             : c->zero_header_bytes();
+    HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, zero_bytes, c->stream));
+    // the fused kernel serves scenes that draw node i with candidate i
+    const bool fused = cull && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
+                       c->n_cand > 0 && c->n_cand <= c->n_nodes && c->level_offsets.size() > 1;
+    if (fused) {
+      TRY(launch_fused(c, bounds_out));
+    } else {
+      if (stages & VKRHIP_STAGE_TRANSFORM) TRY(launch_transform(c));
+      if (cull) TRY(launch_classify(c, bounds_out));
+    }
+    if (cull) TRY(launch_compaction(c));
     if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c));
     if (stages & VKRHIP_STAGE_CANDIDATES) TRY(launch_candidates(c));
   }
@@ -799,14 +876,24 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) {
   if (!c || !out) return VKRHIP_ERR_ARG;
   if (!c->frame_ran) return fail(c, VKRHIP_ERR_STATE, "no frame has run");
   TRY(bind_device(c));
-  uint32_t cnt[CNT_COUNT];
+  static_assert(TF_STAT_SHARDS == STAT_SHARDS && TF_CNT_STRIDE == CNT_COUNT, "shard layout");
+  std::vector<uint32_t> shards(CNT_COUNT * STAT_SHARDS);
+  std::vector<uint64_t> tie_shards((size_t)VKRHIP_MAX_VIEWS * TIE_SHARDS);
   std::memset(out, 0, sizeof(*out));
-  HIP_TRY(c, hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(shards.data(), c->counters(), shards.size() * 4, hipMemcpyDeviceToHost,
+                            c->stream));
   HIP_TRY(c, hipMemcpyAsync(out->views, c->states.p, sizeof(CompactionState) * VKRHIP_MAX_VIEWS,
                             hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out->near_plane_ties, c->ties.p, sizeof(uint64_t) * VKRHIP_MAX_VIEWS,
-                            hipMemcpyDeviceToHost, c->stream));
+  if (c->cfg.tie_epsilon > 0.f)
+    HIP_TRY(c, hipMemcpyAsync(tie_shards.data(), c->ties(), tie_shards.size() * 8,
+                              hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint32_t cnt[CNT_COUNT] = {};
+  for (uint32_t sh = 0; sh < STAT_SHARDS; ++sh)
+    for (int k = 0; k < CNT_COUNT; ++k) cnt[k] += shards[sh * CNT_COUNT + k];
+  for (uint32_t sh = 0; sh < TIE_SHARDS; ++sh)
+    for (uint32_t v = 0; v < VKRHIP_MAX_VIEWS; ++v)
+      out->near_plane_ties[v] += tie_shards[(size_t)sh * VKRHIP_MAX_VIEWS + v];
   const bool culled = (c->last_stages & VKRHIP_STAGE_CULL) != 0;
   out->stats.objects_tested = culled ? (uint32_t)c->n_cand : 0u;
   out->stats.objects_culled_camera = cnt[CNT_CULLED_CAMERA];
@@ -839,7 +926,7 @@ int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   out->transparent_source = c->out_source.p;
   out->gpu_candidates = c->cand_rows.p;
   out->world_bounds = reinterpret_cast<const float *>(c->world_bounds.p);
-  out->device_counts = c->counters.p;
+  out->device_counts = c->counters();
   return VKRHIP_OK;
 }
 
