@@ -85,6 +85,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="flat1m", choices=sorted(WORKLOADS))
     ap.add_argument("--instances", type=int, default=0, help="override instances per GPU")
+    ap.add_argument("--depth", type=int, default=-1, help="override hierarchy depth")
+    ap.add_argument("--cascades", type=int, default=-1, help="override shadow cascade count")
+    ap.add_argument("--probes", type=int, default=-1, help="override extra probe views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -117,6 +120,9 @@ def main() -> int:
     workload = dict(WORKLOADS[args.workload])
     if args.instances:
         workload["n"] = args.instances
+    for key in ("depth", "cascades", "probes"):
+        if getattr(args, key) >= 0:
+            workload[key] = getattr(args, key)
     n = workload["n"]
     sc, vs, extra = build_scene(workload, rank, args.seed)
     planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)

@@ -40,7 +40,8 @@ def needs_build() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("VKRHIP_EXTRA_FLAGS", "").split()  # experiments only
+    cmd = [hipcc()] + HIPCC_FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

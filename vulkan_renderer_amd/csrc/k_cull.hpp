@@ -238,8 +238,10 @@ __device__ __forceinline__ void cull_shared_flush(const CullArgs &a, CullShared 
   const uint32_t t = threadIdx.x;
   const uint32_t rows = a.views * 4u + 1u;
   __syncthreads();
+#ifndef VKR_EXP_NO_TILE_ATOMICS
   for (uint32_t r = t; r < rows; r += blockDim.x)
     if (s.cnt[r]) atomicAdd(&a.tile_counts[(uint64_t)r * a.tiles_stride + tile], s.cnt[r]);
+#endif
   if (t == 0) {
     uint32_t *shard = a.counters + stat_shard();
     if (s.stat[0]) atomicAdd(&shard[CNT_WITHOUT_BOUNDS], s.stat[0]);
@@ -488,9 +490,9 @@ struct ScatterArgs {
 };
 
 __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
-  __shared__ uint32_t s_base[CULL_MAX_ROWS];   // bucket-local index of the tile's first survivor
+  // survivors of (round, wave) per row, turned into bucket-local start indices
+  __shared__ uint32_t s_cnt[CULL_ROUNDS * 4][CULL_MAX_ROWS];
   __shared__ uint32_t s_range[CULL_MAX_ROWS];  // execution_ranges[b].x of the row's view
-  __shared__ uint32_t s_wcnt[4][CULL_MAX_ROWS];
 
   const uint32_t t = threadIdx.x;
   const uint32_t wave = t >> 6;
@@ -498,10 +500,6 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const uint32_t rows = a.views * 4u + 1u;
   const uint64_t tile = blockIdx.x;
-  for (uint32_t r = t; r < rows; r += CULL_BLOCK) {
-    s_base[r] = a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
-    s_range[r] = r < a.views * 4u ? a.states[r >> 2].execution_ranges[r & 3u][0] : 0u;
-  }
   const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
   const uint32_t words = (a.views + 31u) >> 5;
 
@@ -518,18 +516,13 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
     bits0_r[round] = valid ? a.masks[i] : 0u;
   }
 
+  // phase 1: per-(round, wave) survivor counts of every row
 #pragma unroll
   for (int round = 0; round < CULL_ROUNDS; ++round) {
-    const uint64_t base = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK;
-    if (base >= a.n) break;
-    const uint64_t i = base + t;
+    const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
     const bool valid = i < a.n;
-    const uint32_t cf = cf_r[round];
-    const bool tv = tv_r[round];
-    const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
-
-    // phase 1: per-wave survivor counts per row
-    __syncthreads();  // s_wcnt readers of the previous round are done; s_base visible
+    const uint32_t bucket = (cf_r[round] >> CF_BUCKET_SHIFT) & 0xfu;
+    uint32_t *cnt = s_cnt[round * 4 + (int)wave];
     for (uint32_t w = 0; w < words; ++w) {
       const uint32_t bits =
           w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
@@ -539,17 +532,35 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
           const unsigned long long mq = __ballot(pass && bucket == q);
-          if (lane == 0) s_wcnt[wave][v * 4u + q] = (uint32_t)__popcll(mq);
+          if (lane == 0) cnt[v * 4u + q] = (uint32_t)__popcll(mq);
         }
       }
     }
-    {
-      const unsigned long long mt = __ballot(tv);
-      if (lane == 0) s_wcnt[wave][a.views * 4u] = (uint32_t)__popcll(mt);
+    const unsigned long long mt = __ballot(tv_r[round]);
+    if (lane == 0) cnt[a.views * 4u] = (uint32_t)__popcll(mt);
+  }
+  __syncthreads();
+  // exclusive prefix over the 16 (round, wave) slots in candidate order, on top
+  // of the tile's scanned offset
+  for (uint32_t r = t; r < rows; r += CULL_BLOCK) {
+    uint32_t run = a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
+#pragma unroll
+    for (int slot = 0; slot < CULL_ROUNDS * 4; ++slot) {
+      const uint32_t c = s_cnt[slot][r];
+      s_cnt[slot][r] = run;
+      run += c;
     }
-    __syncthreads();
+    s_range[r] = r < a.views * 4u ? a.states[r >> 2].execution_ranges[r & 3u][0] : 0u;
+  }
+  __syncthreads();
 
-    // phase 2: positions
+  // phase 2: positions
+#pragma unroll
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
+    const bool valid = i < a.n;
+    const uint32_t bucket = (cf_r[round] >> CF_BUCKET_SHIFT) & 0xfu;
+    const uint32_t *start = s_cnt[round * 4 + (int)wave];
     for (uint32_t w = 0; w < words; ++w) {
       const uint32_t bits =
           w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
       for (uint32_t v = w * 32u; v < vend; ++v) {
         const bool pass = (bits >> (v & 31u)) & 1u;
         const uint32_t row = v * 4u + (bucket & 3u);
-        // lanes of the same bucket among the survivors below this lane
+        // survivors of the same bucket in the lanes below this one
         uint32_t rank = 0;
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
@@ -565,8 +576,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
           if (bucket == q) rank = (uint32_t)__popcll(mb & lt_mask);
         }
         if (pass) {
-          uint32_t local = s_base[row] + rank;
-          for (uint32_t k = 0; k < wave; ++k) local += s_wcnt[k][row];
+          const uint32_t local = start[row] + rank;
           if (local < cap) {
             const uint64_t slot = (uint64_t)s_range[row] + local;
             if (slot < a.visible_stride)
@@ -575,21 +585,12 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
         }
       }
     }
-    {
-      const uint32_t row = a.views * 4u;
-      const unsigned long long mt = __ballot(tv);
-      if (tv) {
-        uint64_t pos = (uint64_t)s_base[row] + (uint32_t)__popcll(mt & lt_mask);
-        for (uint32_t k = 0; k < wave; ++k) pos += s_wcnt[k][row];
-        if (pos < a.transparent_capacity) {
-          a.keys[pos] = a.tkey[i];
-        }
-      }
+    const bool tv = tv_r[round];
+    const unsigned long long mt = __ballot(tv);
+    if (tv) {
+      const uint64_t pos = (uint64_t)start[a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
+      if (pos < a.transparent_capacity) a.keys[pos] = a.tkey[i];
     }
-    __syncthreads();
-    // advance the tile-local running base by this round's survivors
-    for (uint32_t r = t; r < rows; r += CULL_BLOCK)
-      s_base[r] += s_wcnt[0][r] + s_wcnt[1][r] + s_wcnt[2][r] + s_wcnt[3][r];
   }
 }
 

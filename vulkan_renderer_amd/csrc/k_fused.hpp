@@ -31,6 +31,19 @@ struct FusedArgs {
   CullArgs c;  // c.n = candidates; candidate i <-> node i
 };
 
+// min and max of `p` over the lanes of the wave that hold a parent index
+__device__ __forceinline__ void wave_min_max(uint32_t p, uint32_t &mn, uint32_t &mx) {
+  mn = p;                              // NO_PARENT = 0xffffffff never wins the min
+  mx = p == NO_PARENT ? 0u : p;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t on = (uint32_t)__shfl_xor((int)mn, d, 64);
+    const uint32_t ox = (uint32_t)__shfl_xor((int)mx, d, 64);
+    mn = on < mn ? on : mn;
+    mx = ox > mx ? ox : mx;
+  }
+}
+
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT>
 __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];
@@ -38,19 +51,30 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
   __shared__ uint8_t s_pflags[HAS_PARENT ? FUSED_WINDOW : 1];
   __shared__ uint32_t s_par[HAS_PARENT ? FUSED_BLOCK : 1];
   __shared__ CullShared s;
-  __shared__ uint32_t s_min, s_max, s_updated;
+  __shared__ uint32_t s_wmin[4], s_wmax[4], s_updated;
 
   const uint32_t t = threadIdx.x;
+  const uint32_t col = t & 3u;
   const uint64_t first_block = a.t.begin / FUSED_BLOCK;
   const uint64_t tile_base = (first_block + blockIdx.x) * FUSED_BLOCK;
-  if (t == 0) {
-    s_min = 0xffffffffu;
-    s_max = 0u;
-    s_updated = 0u;
-  }
+  if (t == 0) s_updated = 0u;
   cull_shared_clear(s, a.c.views);
 
-  // cull-phase inputs of this thread's node: requested now, used after the hand-over
+  // ---- every load that depends on nothing is requested first -----------------
+  uint32_t p = NO_PARENT;
+  if (HAS_PARENT) {
+    const uint64_t i = tile_base + t;
+    if (i >= a.t.begin && i < a.t.end) p = a.t.parent[i];
+  }
+  uint8_t f[4];
+  bool valid[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t node = tile_base + (uint32_t)r * 64u + (t >> 2);
+    valid[r] = node >= a.t.begin && node < a.t.end;
+    f[r] = valid[r] ? (uint8_t)(a.t.flags[node] | a.t.force) : (uint8_t)0;
+  }
+  // cull-phase inputs of this thread's node, used after the hand-over
   const uint64_t ci = tile_base + t;
   const bool cvalid = ci >= a.t.begin && ci < a.t.end && ci < a.c.n;
   float4 ls = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -59,76 +83,76 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
     ls = a.c.sphere[ci];
     cf = a.c.cflags[ci];
   }
-  __syncthreads();
 
-  bool window = false;
-  uint32_t pmin = 0;
-  if (HAS_PARENT) {
-    const uint64_t i = tile_base + t;
-    uint32_t p = NO_PARENT;
-    if (i >= a.t.begin && i < a.t.end) p = a.t.parent[i];
-    s_par[t] = p;
-    if (p != NO_PARENT) {
-      atomicMin(&s_min, p);
-      atomicMax(&s_max, p);
-    }
-    __syncthreads();
-    pmin = s_min;
-    const uint32_t pmax = s_max;
-    window = pmin <= pmax && (pmax - pmin) < (uint32_t)FUSED_WINDOW;
-    if (window) {
-      const uint32_t span = pmax - pmin + 1u;
-      const float4 *src = a.t.world + (uint64_t)pmin * 4u;
-      for (uint32_t k = t; k < span * 4u; k += FUSED_BLOCK) s_pworld[k] = src[k];
-      for (uint32_t k = t; k < span; k += FUSED_BLOCK) s_pflags[k] = a.t.flags[(uint64_t)pmin + k];
-    }
-    __syncthreads();
-  }
-
-  // ---- transform phase ----------------------------------------------------
-  const uint32_t col = t & 3u;
-  uint8_t f[4];
-  bool valid[4];
-  uint32_t par[4];
+  // ---- matrix loads that the node's own flags decide ---------------------------
+  // own flags dirty -> the local column; clean -> the stored world column (the
+  // cull phase needs it unless the parent turns out to have moved, see below)
   float4 lcol[4], wold[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
-    const uint64_t node = tile_base + slot;
-    valid[r] = node >= a.t.begin && node < a.t.end;
-    f[r] = valid[r] ? (uint8_t)(a.t.flags[node] | a.t.force) : (uint8_t)0;
-    par[r] = NO_PARENT;
-    if (HAS_PARENT) par[r] = s_par[slot];
-  }
-  // pass 1 flag handling and the parent-updated test (vkr_scene_system.c:592-603,1310-1316)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    f[r] &= (uint8_t)~F_WORLD_UPDATED;
-    if (HAS_PARENT && valid[r] && par[r] != NO_PARENT) {
-      const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.t.flags[par[r]];
-      if (pf & F_WORLD_UPDATED) f[r] |= F_DIRTY_WORLD;
-    }
-  }
-  // loads: the local column when the world matrix is recomputed, the stored
-  // world column otherwise (the cull phase needs one of them)
+  bool have_local[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t node = tile_base + (uint32_t)r * 64u + (t >> 2);
+    f[r] &= (uint8_t)~F_WORLD_UPDATED;  // pass 1, vkr_scene_system.c:596
     lcol[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     wold[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    have_local[r] = false;
     if (valid[r]) {
-      if (f[r] & F_DIRTY_LOCAL) {
+      if (f[r] & F_DIRTY_LOCAL) {  // pass 1, vkr_scene_system.c:598-602
         if (a.t.pos != nullptr) {
           lcol[r] = local_col_from_trs(a.t.pos[node], a.t.quat[node], a.t.scale[node], col);
           a.t.local[node * 4u + col] = lcol[r];
         } else {
           lcol[r] = a.t.local[node * 4u + col];
         }
+        have_local[r] = true;
         f[r] = (uint8_t)((f[r] & ~F_DIRTY_LOCAL) | F_DIRTY_WORLD);
       } else if (f[r] & F_DIRTY_WORLD) {
         lcol[r] = a.t.local[node * 4u + col];
+        have_local[r] = true;
       } else {
         wold[r] = a.t.world[node * 4u + col];
+      }
+    }
+  }
+
+  // ---- parent window ---------------------------------------------------------------
+  bool window = false;
+  uint32_t pmin = 0;
+  if (HAS_PARENT) {
+    s_par[t] = p;
+    uint32_t wmn, wmx;
+    wave_min_max(p, wmn, wmx);
+    if ((t & 63u) == 0) {
+      s_wmin[t >> 6] = wmn;
+      s_wmax[t >> 6] = wmx;
+    }
+    __syncthreads();
+    pmin = min(min(s_wmin[0], s_wmin[1]), min(s_wmin[2], s_wmin[3]));
+    const uint32_t pmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    window = pmin != NO_PARENT && (pmax - pmin) < (uint32_t)FUSED_WINDOW;
+    if (window) {
+      const uint32_t span = pmax - pmin + 1u;
+      const float4 *src = a.t.world + (uint64_t)pmin * 4u;
+      for (uint32_t k = t; k < span * 4u; k += FUSED_BLOCK) s_pworld[k] = src[k];
+      for (uint32_t k = t; k < span; k += FUSED_BLOCK) s_pflags[k] = a.t.flags[(uint64_t)pmin + k];
+    }
+  }
+  __syncthreads();  // window staged, accumulators cleared
+
+  // ---- transform phase ----------------------------------------------------------------
+  uint32_t par[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
+    const uint64_t node = tile_base + slot;
+    par[r] = NO_PARENT;
+    if (HAS_PARENT) par[r] = s_par[slot];
+    // deferred dirty propagation, vkr_scene_system.c:1310-1316
+    if (HAS_PARENT && valid[r] && par[r] != NO_PARENT) {
+      const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.t.flags[par[r]];
+      if (pf & F_WORLD_UPDATED) {
+        f[r] |= F_DIRTY_WORLD;
+        if (!have_local[r]) lcol[r] = a.t.local[node * 4u + col];  // the parent moved after all
       }
     }
   }
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
     const uint64_t node = tile_base + slot;
     float4 wcol = wold[r];
     bool did_update = false;
-    if (valid[r] && (f[r] & F_DIRTY_WORLD)) {
+    if (valid[r] && (f[r] & F_DIRTY_WORLD)) {  // pass 2, vkr_scene_system.c:1319-1336
       wcol = lcol[r];
       if (HAS_PARENT && par[r] != NO_PARENT) {
         float4 a0, a1, a2, a3;

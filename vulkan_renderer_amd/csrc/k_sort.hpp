@@ -120,20 +120,33 @@ __device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *
   const uint32_t t = threadIdx.x;
   const uint32_t wave = t >> 6;
   const uint32_t lane = t & 63u;
+  // A single tile's digit totals fall out of the ranking below; only a longer
+  // array needs the histogram up front.
+  const bool single = count <= SMALL_KEYS;
   __syncthreads();  // src is complete, the previous pass is done with s
   if (t < SORT_RADIX) s.base[t] = 0u;
   if (t == 0) s.skip = 0u;
-  __syncthreads();
-  for (uint32_t idx = t; idx < count; idx += SMALL_THREADS)
-    atomicAdd(&s.base[(uint32_t)(src[idx] >> shift) & 0xffu], 1u);
-  __syncthreads();
-  const uint32_t tot = t < SORT_RADIX ? s.base[t] : 0u;
-  if (t < SORT_RADIX && tot == count) s.skip = 1u;
-  uint32_t total;
-  const uint32_t ex = block_exclusive_scan(tot, s.wave, &total);
-  __syncthreads();
-  if (t < SORT_RADIX) s.base[t] = ex;
-  if (s.skip) return false;  // uniform: read after the barrier above
+  if (!single) {
+    __syncthreads();
+    // wave-aggregated: one LDS atomic per group of equal digits, not per key
+    // (the high bytes of a float key take very few values)
+    for (uint32_t base = 0; base < count; base += SMALL_THREADS) {
+      const uint32_t idx = base + t;
+      const bool valid = idx < count;
+      const uint32_t digit = valid ? (uint32_t)(src[idx] >> shift) & 0xffu : 0u;
+      const unsigned long long peers = match_digit(digit, valid);
+      if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull)
+        atomicAdd(&s.base[digit], (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    const uint32_t tot = t < SORT_RADIX ? s.base[t] : 0u;
+    if (t < SORT_RADIX && tot == count) s.skip = 1u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(tot, s.wave, &total);
+    __syncthreads();
+    if (t < SORT_RADIX) s.base[t] = ex;
+    if (s.skip) return false;  // uniform: read after the barrier above
+  }
 
   for (uint32_t tile_base = 0; tile_base < count; tile_base += SMALL_KEYS) {
     __syncthreads();  // s.base updated, previous tile's whist readers done
@@ -164,6 +177,19 @@ __device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *
       }
     }
     __syncthreads();
+    if (single) {
+      uint32_t tot = 0;
+      if (t < SORT_RADIX) {
+#pragma unroll
+        for (int w = 0; w < SMALL_WAVES; ++w) tot += s.whist[w][t];
+        if (tot == count) s.skip = 1u;  // every key has this digit: identity permutation
+      }
+      uint32_t total;
+      const uint32_t ex = block_exclusive_scan(tot, s.wave, &total);
+      if (t < SORT_RADIX) s.base[t] = ex;
+      __syncthreads();
+      if (s.skip) return false;  // uniform
+    }
     if (t < SORT_RADIX) {
       uint32_t run = s.base[t];
 #pragma unroll
