@@ -152,17 +152,32 @@ __host__ __device__ __forceinline__ float4 local_col_from_trs(float4 p, float4 q
   return mat4_mul_col(tr0, tr1, tr2, tr3, b);
 }
 
+// Per-launch tables that every lane reads at the same index (frustum planes,
+// view gates, the camera matrix) are read through the constant address space:
+// the compiler may then assume no store of the launch aliases them and fetches
+// them with scalar loads into SGPRs instead of one vector load per lane.
+template <typename T>
+using uniform_ptr = const T __attribute__((address_space(4))) *;
+template <typename T>
+__device__ __forceinline__ uniform_ptr<T> as_uniform(const T *p) {
+  return (uniform_ptr<T>)(uintptr_t)p;
+}
+__device__ __forceinline__ uniform_ptr<float> as_uniform(const float4 *p) {
+  return (uniform_ptr<float>)(uintptr_t)p;
+}
+
 // vkr_frustum_test_sphere, lib/src/math/vkr_frustum.c:68-84, without the early
-// return (the result is the conjunction either way). planes = 6 x (n, d).
+// return (the result is the conjunction either way). planes = 6 x (nx,ny,nz,d).
 // A NaN distance or radius compares false and keeps the sphere visible.
-__device__ __forceinline__ bool sphere_visible(const float4 *__restrict__ planes, float cx,
-                                               float cy, float cz, float radius) {
+__device__ __forceinline__ bool sphere_visible(uniform_ptr<float> planes, float cx, float cy,
+                                               float cz, float radius) {
   bool culled = false;
   const float neg_r = -radius;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const float4 p = planes[i];
-    const float dist = dot3(p.x, p.y, p.z, cx, cy, cz) + p.w;
+    const float dist =
+        dot3(planes[i * 4 + 0], planes[i * 4 + 1], planes[i * 4 + 2], cx, cy, cz) +
+        planes[i * 4 + 3];
     culled = culled || (dist < neg_r);
   }
   return !culled;

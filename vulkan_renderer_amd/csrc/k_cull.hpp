@@ -164,16 +164,21 @@ __device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared
   // ordinary blend rows: application.h:790-803 (camera frustum = view 0 planes)
   const bool blend_row = valid && (cf & CF_BLEND) && !(cf & CF_TRANSMISSIVE);
   bool tv = false;
-  if (blend_row) tv = bounds_valid ? sphere_visible(a.planes, c.x, c.y, c.z, radius) : true;
+  const uniform_ptr<float> planes = as_uniform(a.planes);
+  const uniform_ptr<float> tie_eps = as_uniform(a.tie_eps);
+  const uniform_ptr<uint32_t> required = as_uniform(a.required);
+  if (blend_row) tv = bounds_valid ? sphere_visible(planes, c.x, c.y, c.z, radius) : true;
   if (valid) a.tvis[i] = tv ? 1u : 0u;
   if (tv) {
     // application_transparent_depth + application_pack_transparent_sort_key,
-    // application.h:573-587. The world centre is the one computed above.
+    // application.h:573-587. The world centre is the one computed above; only
+    // the z row of the view matrix takes part.
+    const uniform_ptr<float> vm = as_uniform(a.view);
     Mat4 view;
-    view.c[0] = a.view[0];
-    view.c[1] = a.view[1];
-    view.c[2] = a.view[2];
-    view.c[3] = a.view[3];
+    view.c[0] = make_float4(0.f, 0.f, vm[2], 0.f);
+    view.c[1] = make_float4(0.f, 0.f, vm[6], 0.f);
+    view.c[2] = make_float4(0.f, 0.f, vm[10], 0.f);
+    view.c[3] = make_float4(0.f, 0.f, vm[14], 0.f);
     const float vz = mat4_mul_vec4_z(view, c.x, c.y, c.z, 1.0f);
     float depth = -vz;
     depth = depth > 0.0f ? depth : 0.0f;
@@ -197,21 +202,25 @@ __device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared
 
   // views: deferred.slang:316-351
   const uint32_t words = (a.views + 31u) >> 5;
+  unsigned long long in_bucket[4];  // lanes of the wave per state bucket (wave-uniform)
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; ++q) in_bucket[q] = __ballot(bucket == q);
   for (uint32_t w = 0; w < words; ++w) {
     uint32_t bits = 0u;
     const uint32_t vend = min(a.views, (w + 1u) * 32u);
     for (uint32_t v = w * 32u; v < vend; ++v) {
-      const uint32_t req = a.required[v];
+      const uint32_t req = required[v];
       bool pass = valid && bucket < 4u && (cf & req) == req;
       bool tie = false;
       if (pass && bounds_valid) {
-        pass = sphere_visible(a.planes + v * 6u, c.x, c.y, c.z, radius);
+        const uniform_ptr<float> vp = planes + v * 24u;
+        pass = sphere_visible(vp, c.x, c.y, c.z, radius);
         if (TIES) {
 #pragma unroll
           for (int p = 0; p < 6; ++p) {
-            const float4 pl = a.planes[v * 6u + p];
-            const float dist = dot3(pl.x, pl.y, pl.z, c.x, c.y, c.z) + pl.w;
-            tie = tie || (fabsf(dist + radius) <= a.tie_eps[v * 6u + p]);
+            const float dist =
+                dot3(vp[p * 4 + 0], vp[p * 4 + 1], vp[p * 4 + 2], c.x, c.y, c.z) + vp[p * 4 + 3];
+            tie = tie || (fabsf(dist + radius) <= tie_eps[v * 6u + p]);
           }
         }
       }
@@ -220,10 +229,13 @@ __device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared
         if (leader && mtie) atomicAdd(&s.ties[v], (uint32_t)__popcll(mtie));
       }
       if (pass) bits |= 1u << (v & 31u);
+      const unsigned long long mp = __ballot(pass);
+      if (leader && mp) {
 #pragma unroll
-      for (uint32_t q = 0; q < 4u; ++q) {
-        const unsigned long long mq = __ballot(pass && bucket == q);
-        if (leader && mq) atomicAdd(&s.cnt[v * 4u + q], (uint32_t)__popcll(mq));
+        for (uint32_t q = 0; q < 4u; ++q) {
+          const uint32_t nq = (uint32_t)__popcll(mp & in_bucket[q]);
+          if (nq) atomicAdd(&s.cnt[v * 4u + q], nq);
+        }
       }
     }
     if (valid) a.masks[(uint64_t)w * a.mask_stride + i] = bits;
@@ -523,16 +535,19 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
     const bool valid = i < a.n;
     const uint32_t bucket = (cf_r[round] >> CF_BUCKET_SHIFT) & 0xfu;
     uint32_t *cnt = s_cnt[round * 4 + (int)wave];
+    unsigned long long in_bucket[4];  // lanes of the wave per state bucket
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) in_bucket[q] = __ballot(bucket == q);
     for (uint32_t w = 0; w < words; ++w) {
       const uint32_t bits =
           w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
       const uint32_t vend = min(a.views, (w + 1u) * 32u);
       for (uint32_t v = w * 32u; v < vend; ++v) {
-        const bool pass = (bits >> (v & 31u)) & 1u;
+        const unsigned long long mp = __ballot((bits >> (v & 31u)) & 1u);
+        if (lane == 0) {
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-          const unsigned long long mq = __ballot(pass && bucket == q);
-          if (lane == 0) cnt[v * 4u + q] = (uint32_t)__popcll(mq);
+          for (uint32_t q = 0; q < 4u; ++q)
+            cnt[v * 4u + q] = (uint32_t)__popcll(mp & in_bucket[q]);
         }
       }
     }
@@ -561,6 +576,12 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
     const bool valid = i < a.n;
     const uint32_t bucket = (cf_r[round] >> CF_BUCKET_SHIFT) & 0xfu;
     const uint32_t *start = s_cnt[round * 4 + (int)wave];
+    unsigned long long below_same_bucket = 0ull;  // lower lanes holding this lane's bucket
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+      const unsigned long long mb = __ballot(bucket == q);
+      if (bucket == q) below_same_bucket = mb & lt_mask;
+    }
     for (uint32_t w = 0; w < words; ++w) {
       const uint32_t bits =
           w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
@@ -569,12 +590,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
         const bool pass = (bits >> (v & 31u)) & 1u;
         const uint32_t row = v * 4u + (bucket & 3u);
         // survivors of the same bucket in the lanes below this one
-        uint32_t rank = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-          const unsigned long long mb = __ballot(pass && bucket == q);
-          if (bucket == q) rank = (uint32_t)__popcll(mb & lt_mask);
-        }
+        const unsigned long long mp = __ballot(pass);
+        const uint32_t rank = (uint32_t)__popcll(mp & below_same_bucket);
         if (pass) {
           const uint32_t local = start[row] + rank;
           if (local < cap) {

@@ -5,18 +5,26 @@
 // just produced is classified before it leaves the CU: it is written to HBM once
 // (world[] is an output) and never re-read by a separate cull launch. Per node
 // the HBM traffic is local 64 B + flags 1 B in, world 64 B + flags 1 B out,
-// sphere 16 B + candidate word 4 B in, view-mask word(s) + visibility byte out.
+// sphere 16 B + candidate word 4 B in, view-mask word(s) + visibility byte out
+// (+ parent index 4 B below the root level).
 //
-// Thread mapping inside a block of 256 nodes:
+// A block owns one 1024-node count tile (aligned to 1024 in the global node
+// index) and walks it in four rounds of 256 nodes. The loads of round r+1 are
+// issued before round r is consumed, so a block always has a round's worth of
+// HBM requests in flight while it computes.
+//
+// Thread mapping inside a round:
 //   transform phase  4 lanes per node, lane j owns column j, four sub-rounds of
-//                    64 nodes; all loads of the four sub-rounds are issued
-//                    before the first use;
+//                    64 nodes: every wave load/store covers 1 KiB of consecutive
+//                    bytes;
 //   hand-over        the world columns go to LDS with an 80-byte node stride
 //                    (conflict-free 16-byte reads);
 //   cull phase       one thread per node reads its four columns back and runs
 //                    classify_candidate().
-// Blocks are aligned to multiples of 256 in the global node index so that every
-// block falls into exactly one 1024-candidate count tile.
+// Parent world matrices of a round are staged in LDS when the round's parents
+// form a window of at most FUSED_WINDOW nodes (siblings are contiguous and
+// parents ascend in the BFS node order, so 256 nodes of fan-out >= 2 qualify);
+// otherwise lanes read their parent through the cache hierarchy.
 #pragma once
 #include "k_cull.hpp"
 #include "k_transform.hpp"
@@ -24,7 +32,8 @@
 namespace vkr {
 
 constexpr int FUSED_BLOCK = 256;
-constexpr int FUSED_WINDOW = 128;  // LDS-staged parent window (nodes)
+constexpr int FUSED_ROUNDS = CULL_TILE / FUSED_BLOCK;  // 4
+constexpr int FUSED_WINDOW = 128;                      // LDS-staged parent window (nodes)
 
 struct FusedArgs {
   TransformArgs t;
@@ -33,7 +42,7 @@ struct FusedArgs {
 
 // min and max of `p` over the lanes of the wave that hold a parent index
 __device__ __forceinline__ void wave_min_max(uint32_t p, uint32_t &mn, uint32_t &mx) {
-  mn = p;                              // NO_PARENT = 0xffffffff never wins the min
+  mn = p;  // NO_PARENT = 0xffffffff never wins the min
   mx = p == NO_PARENT ? 0u : p;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -44,6 +53,102 @@ __device__ __forceinline__ void wave_min_max(uint32_t p, uint32_t &mn, uint32_t 
   }
 }
 
+// What one thread loads for one round, in two dependent steps: the head (flags,
+// parent index, cull inputs) depends on nothing; the matrix columns are picked
+// by the flags of the head. Both steps are unconditional loads from clamped
+// indices whose results are masked with integer arithmetic afterwards (a
+// select on a loaded value would be turned back into a branch around the load,
+// and every such branch waits for its own load), so all loads of a step are
+// issued back to back and the rounds can be software-pipelined. Positions are
+// 32-bit offsets into the block's 1024-node tile; [lo, hi) is the part of the
+// tile that belongs to the level.
+struct FusedHead {
+  uint32_t f[4];  // node flag bytes; after fused_resolve_head: pass-1 state, 0 outside the level
+  uint32_t p;     // parent of node (round base + thread)
+  float4 ls;      // local sphere of candidate (round base + thread)
+  uint32_t cf;
+};
+
+__device__ __forceinline__ uint32_t clamp_rel(uint32_t rel, uint32_t lo, uint32_t hi) {
+  return min(max(rel, lo), hi - 1u);
+}
+__device__ __forceinline__ uint32_t in_range_mask(uint32_t rel, uint32_t lo, uint32_t hi) {
+  return (rel >= lo && rel < hi) ? 0xffffffffu : 0u;
+}
+
+template <bool HAS_PARENT>
+__device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t tile_base,
+                                                 uint32_t lo, uint32_t hi, uint32_t rbase,
+                                                 FusedHead &h) {
+  const uint32_t t = threadIdx.x;
+  const uint64_t i = tile_base + clamp_rel(rbase + t, lo, hi);
+  h.p = NO_PARENT;
+  if (HAS_PARENT) h.p = a.t.parent[i];
+  const uint64_t ci = min(i, a.c.n - 1u);
+  h.ls = a.c.sphere[ci];
+  h.cf = a.c.cflags[ci];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    h.f[r] = a.t.flags[tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi)];
+}
+
+// Waits for the head's loads. Applies the bulk dirty bits and pass 1's clearing
+// of WORLD_UPDATED (vkr_scene_system.c:596) and blanks lanes outside the level.
+__device__ __forceinline__ void fused_resolve_head(const FusedArgs &a, uint64_t tile_base,
+                                                   uint32_t lo, uint32_t hi, uint32_t rbase,
+                                                   FusedHead &h) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t rel = rbase + t;
+  uint32_t m = in_range_mask(rel, lo, hi);
+  h.p |= ~m;  // NO_PARENT outside the level
+  if (tile_base + rel >= a.c.n) m = 0u;
+  h.cf = (h.cf & m) | (0xf0u & ~m);  // invalid bucket: fails every gate
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t mr = in_range_mask(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi);
+    h.f[r] = ((h.f[r] | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & mr;
+  }
+}
+
+struct FusedBody {
+  float4 m[4];          // local column (have_local bit r) or stored world column, per sub-round
+  uint32_t have_local;  // bit r
+};
+
+// Needs a resolved head. The node's own flags pick the matrix to fetch: dirty ->
+// the local column; clean -> the stored world column (the cull phase needs it
+// unless the parent turns out to have moved, which is handled when the parents
+// are known).
+__device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t tile_base,
+                                                 uint32_t lo, uint32_t hi, uint32_t rbase,
+                                                 FusedHead &h, FusedBody &b) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t col = t & 3u;
+  b.have_local = 0u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint64_t node = tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi);
+    const bool hl = (h.f[r] & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
+    const float4 *src = hl ? a.t.local : a.t.world;
+    b.m[r] = src[node * 4u + col];
+    b.have_local |= hl ? (1u << r) : 0u;
+  }
+  // pass 1, vkr_scene_system.c:598-602: a changed TRS rebuilds the local matrix
+  if (a.t.pos != nullptr) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (h.f[r] & F_DIRTY_LOCAL) {
+        const uint64_t node = tile_base + rbase + (uint32_t)r * 64u + (t >> 2);
+        b.m[r] = local_col_from_trs(a.t.pos[node], a.t.quat[node], a.t.scale[node], col);
+        a.t.local[node * 4u + col] = b.m[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)  // DIRTY_LOCAL becomes DIRTY_WORLD
+    h.f[r] = (h.f[r] | ((h.f[r] & F_DIRTY_LOCAL) << 1)) & ~(uint32_t)F_DIRTY_LOCAL;
+}
+
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT>
 __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];
@@ -52,159 +157,141 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
   __shared__ uint32_t s_par[HAS_PARENT ? FUSED_BLOCK : 1];
   __shared__ CullShared s;
   __shared__ uint32_t s_wmin[4], s_wmax[4], s_updated;
+  static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
 
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
-  const uint64_t first_block = a.t.begin / FUSED_BLOCK;
-  const uint64_t tile_base = (first_block + blockIdx.x) * FUSED_BLOCK;
+  const uint64_t tile = a.t.begin / CULL_TILE + blockIdx.x;
+  const uint64_t tile_base = tile * CULL_TILE;
+  // the level's part of this tile, as offsets into the tile (lo < hi by the grid size)
+  const uint32_t lo = a.t.begin > tile_base ? (uint32_t)(a.t.begin - tile_base) : 0u;
+  const uint32_t hi = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tile_base);
   if (t == 0) s_updated = 0u;
   cull_shared_clear(s, a.c.views);
 
-  // ---- every load that depends on nothing is requested first -----------------
-  uint32_t p = NO_PARENT;
-  if (HAS_PARENT) {
-    const uint64_t i = tile_base + t;
-    if (i >= a.t.begin && i < a.t.end) p = a.t.parent[i];
-  }
-  uint8_t f[4];
-  bool valid[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t node = tile_base + (uint32_t)r * 64u + (t >> 2);
-    valid[r] = node >= a.t.begin && node < a.t.end;
-    f[r] = valid[r] ? (uint8_t)(a.t.flags[node] | a.t.force) : (uint8_t)0;
-  }
-  // cull-phase inputs of this thread's node, used after the hand-over
-  const uint64_t ci = tile_base + t;
-  const bool cvalid = ci >= a.t.begin && ci < a.t.end && ci < a.c.n;
-  float4 ls = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t cf = 0xf0u;
-  if (cvalid) {
-    ls = a.c.sphere[ci];
-    cf = a.c.cflags[ci];
-  }
-
-  // ---- matrix loads that the node's own flags decide ---------------------------
-  // own flags dirty -> the local column; clean -> the stored world column (the
-  // cull phase needs it unless the parent turns out to have moved, see below)
-  float4 lcol[4], wold[4];
-  bool have_local[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t node = tile_base + (uint32_t)r * 64u + (t >> 2);
-    f[r] &= (uint8_t)~F_WORLD_UPDATED;  // pass 1, vkr_scene_system.c:596
-    lcol[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    wold[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    have_local[r] = false;
-    if (valid[r]) {
-      if (f[r] & F_DIRTY_LOCAL) {  // pass 1, vkr_scene_system.c:598-602
-        if (a.t.pos != nullptr) {
-          lcol[r] = local_col_from_trs(a.t.pos[node], a.t.quat[node], a.t.scale[node], col);
-          a.t.local[node * 4u + col] = lcol[r];
-        } else {
-          lcol[r] = a.t.local[node * 4u + col];
-        }
-        have_local[r] = true;
-        f[r] = (uint8_t)((f[r] & ~F_DIRTY_LOCAL) | F_DIRTY_WORLD);
-      } else if (f[r] & F_DIRTY_WORLD) {
-        lcol[r] = a.t.local[node * 4u + col];
-        have_local[r] = true;
-      } else {
-        wold[r] = a.t.world[node * 4u + col];
-      }
-    }
-  }
-
-  // ---- parent window ---------------------------------------------------------------
-  bool window = false;
-  uint32_t pmin = 0;
-  if (HAS_PARENT) {
-    s_par[t] = p;
-    uint32_t wmn, wmx;
-    wave_min_max(p, wmn, wmx);
-    if ((t & 63u) == 0) {
-      s_wmin[t >> 6] = wmn;
-      s_wmax[t >> 6] = wmx;
-    }
-    __syncthreads();
-    pmin = min(min(s_wmin[0], s_wmin[1]), min(s_wmin[2], s_wmin[3]));
-    const uint32_t pmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    window = pmin != NO_PARENT && (pmax - pmin) < (uint32_t)FUSED_WINDOW;
-    if (window) {
-      const uint32_t span = pmax - pmin + 1u;
-      const float4 *src = a.t.world + (uint64_t)pmin * 4u;
-      for (uint32_t k = t; k < span * 4u; k += FUSED_BLOCK) s_pworld[k] = src[k];
-      for (uint32_t k = t; k < span; k += FUSED_BLOCK) s_pflags[k] = a.t.flags[(uint64_t)pmin + k];
-    }
-  }
-  __syncthreads();  // window staged, accumulators cleared
-
-  // ---- transform phase ----------------------------------------------------------------
-  uint32_t par[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
-    const uint64_t node = tile_base + slot;
-    par[r] = NO_PARENT;
-    if (HAS_PARENT) par[r] = s_par[slot];
-    // deferred dirty propagation, vkr_scene_system.c:1310-1316
-    if (HAS_PARENT && valid[r] && par[r] != NO_PARENT) {
-      const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.t.flags[par[r]];
-      if (pf & F_WORLD_UPDATED) {
-        f[r] |= F_DIRTY_WORLD;
-        if (!have_local[r]) lcol[r] = a.t.local[node * 4u + col];  // the parent moved after all
-      }
-    }
+  // rounds of the tile that overlap the level (block-uniform)
+  auto active = [&](int r) {
+    return r < FUSED_ROUNDS && (uint32_t)r * FUSED_BLOCK < hi && (uint32_t)(r + 1) * FUSED_BLOCK > lo;
+  };
+  // Three-deep software pipeline: while round r is computed, the matrices of
+  // round r+1 and the head of round r+2 are in flight.
+  FusedHead head_next, head_after;
+  FusedBody body_next;
+  if (active(0)) fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, 0u, head_next);
+  if (active(1)) fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
+  if (active(0)) {
+    fused_resolve_head(a, tile_base, lo, hi, 0u, head_next);
+    fused_issue_body(a, tile_base, lo, hi, 0u, head_next, body_next);
   }
   uint32_t updated_here = 0;
+
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
-    const uint64_t node = tile_base + slot;
-    float4 wcol = wold[r];
-    bool did_update = false;
-    if (valid[r] && (f[r] & F_DIRTY_WORLD)) {  // pass 2, vkr_scene_system.c:1319-1336
-      wcol = lcol[r];
-      if (HAS_PARENT && par[r] != NO_PARENT) {
-        float4 a0, a1, a2, a3;
-        if (window) {
-          const float4 *pw = s_pworld + (par[r] - pmin) * 4u;
-          a0 = pw[0];
-          a1 = pw[1];
-          a2 = pw[2];
-          a3 = pw[3];
-        } else {
-          const float4 *pw = a.t.world + (uint64_t)par[r] * 4u;
-          a0 = pw[0];
-          a1 = pw[1];
-          a2 = pw[2];
-          a3 = pw[3];
-        }
-        wcol = mat4_mul_col(a0, a1, a2, a3, lcol[r]);
-      }
-      a.t.world[node * 4u + col] = wcol;
-      f[r] = (uint8_t)((f[r] & ~F_DIRTY_WORLD) | F_WORLD_UPDATED);
-      did_update = true;
+  for (int round = 0; round < FUSED_ROUNDS; ++round) {
+    const uint32_t rbase = (uint32_t)round * FUSED_BLOCK;
+    const uint64_t base = tile_base + rbase;
+    FusedHead hd = head_next;
+    FusedBody cur = body_next;
+    head_next = head_after;
+    if (active(round + 1)) {
+      fused_resolve_head(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
+      fused_issue_body(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
-    if (valid[r] && col == 0) a.t.flags[node] = f[r];
-    s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
-    const unsigned long long m = __ballot(did_update && col == 0);
-    if ((t & 63u) == 0) updated_here += (uint32_t)__popcll(m);
+    if (active(round + 2))
+      fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, rbase + 2 * FUSED_BLOCK, head_after);
+    if (!active(round)) continue;
+
+    // ---- parent window -------------------------------------------------------
+    bool window = false;
+    uint32_t pmin = 0;
+    if (HAS_PARENT) {
+      s_par[t] = hd.p;
+      uint32_t wmn, wmx;
+      wave_min_max(hd.p, wmn, wmx);
+      if ((t & 63u) == 0) {
+        s_wmin[t >> 6] = wmn;
+        s_wmax[t >> 6] = wmx;
+      }
+      __syncthreads();  // also: the previous round's readers of s_pworld are done
+      pmin = min(min(s_wmin[0], s_wmin[1]), min(s_wmin[2], s_wmin[3]));
+      const uint32_t pmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+      window = pmin != NO_PARENT && (pmax - pmin) < (uint32_t)FUSED_WINDOW;
+      if (window) {
+        const uint32_t span = pmax - pmin + 1u;
+        const float4 *src = a.t.world + (uint64_t)pmin * 4u;
+        for (uint32_t k = t; k < span * 4u; k += FUSED_BLOCK) s_pworld[k] = src[k];
+        for (uint32_t k = t; k < span; k += FUSED_BLOCK)
+          s_pflags[k] = a.t.flags[(uint64_t)pmin + k];
+      }
+    }
+    __syncthreads();  // window staged; accumulators cleared; s_mat free again
+
+    // ---- transform phase -------------------------------------------------------
+    uint32_t par[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
+      const uint64_t node = base + slot;
+      par[r] = NO_PARENT;
+      if (HAS_PARENT) par[r] = s_par[slot];
+      // deferred dirty propagation, vkr_scene_system.c:1310-1316
+      if (HAS_PARENT && par[r] != NO_PARENT) {
+        const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.t.flags[par[r]];
+        if (pf & F_WORLD_UPDATED) {
+          hd.f[r] |= F_DIRTY_WORLD;
+          if (!(cur.have_local & (1u << r))) cur.m[r] = a.t.local[node * 4u + col];  // parent moved
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
+      const uint64_t node = base + slot;
+      const bool valid = rbase + slot >= lo && rbase + slot < hi;
+      float4 wcol = cur.m[r];
+      bool did_update = false;
+      if (hd.f[r] & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
+        if (HAS_PARENT && par[r] != NO_PARENT) {
+          float4 a0, a1, a2, a3;
+          if (window) {
+            const float4 *pw = s_pworld + (par[r] - pmin) * 4u;
+            a0 = pw[0];
+            a1 = pw[1];
+            a2 = pw[2];
+            a3 = pw[3];
+          } else {
+            const float4 *pw = a.t.world + (uint64_t)par[r] * 4u;
+            a0 = pw[0];
+            a1 = pw[1];
+            a2 = pw[2];
+            a3 = pw[3];
+          }
+          wcol = mat4_mul_col(a0, a1, a2, a3, cur.m[r]);
+        }
+        a.t.world[node * 4u + col] = wcol;
+        hd.f[r] = (hd.f[r] & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
+        did_update = true;
+      }
+      if (valid && col == 0) a.t.flags[node] = (uint8_t)hd.f[r];
+      s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
+      const unsigned long long m = __ballot(did_update && col == 0);
+      updated_here += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+
+    // ---- cull phase ------------------------------------------------------------
+    Mat4 m;
+    {
+      const float4 *p = s_mat + t * MAT_LDS_STRIDE;
+      m.c[0] = p[0];
+      m.c[1] = p[1];
+      m.c[2] = p[2];
+      m.c[3] = p[3];
+    }
+    const bool cvalid = rbase + t >= lo && rbase + t < hi && base + t < a.c.n;
+    classify_candidate<TIES, BOUNDS_OUT>(a.c, s, base + t, cvalid, m, hd.ls, hd.cf);
   }
   if ((t & 63u) == 0 && updated_here) atomicAdd(&s_updated, updated_here);
-  __syncthreads();
-
-  // ---- cull phase -----------------------------------------------------------
-  Mat4 m;
-  {
-    const float4 *p = s_mat + t * MAT_LDS_STRIDE;
-    m.c[0] = p[0];
-    m.c[1] = p[1];
-    m.c[2] = p[2];
-    m.c[3] = p[3];
-  }
-  classify_candidate<TIES, BOUNDS_OUT>(a.c, s, ci, cvalid, m, ls, cf);
-  cull_shared_flush<TIES>(a.c, s, tile_base / CULL_TILE);
+  cull_shared_flush<TIES>(a.c, s, tile);
   if (t == 0 && s_updated) atomicAdd(a.t.counters + stat_shard() + CNT_NODES_UPDATED, s_updated);
 }
 

@@ -667,7 +667,7 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.c = cull_args(c);
     if (a.t.end == a.t.begin) continue;
     const unsigned grid =
-        (unsigned)(ceil_div(a.t.end, FUSED_BLOCK) - a.t.begin / FUSED_BLOCK);
+        (unsigned)(ceil_div(a.t.end, CULL_TILE) - a.t.begin / CULL_TILE);
     if (l == 0 || !c->parent.p)
       launch_fused_variant<false>(c, a, grid, ties, bounds_out);
     else
