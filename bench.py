@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+EVENT_STRIDE = 4        # timed steps per HIP-event sample of the dominant kernel
 
 WORKLOADS = {
     # name: (instances per GPU, hierarchy depth, cascades, extra probe views)
@@ -162,12 +163,20 @@ def main() -> int:
     fence()
     warm = hs.timers(reset=True)
     dominant = max(("transform", "classify", "fused"), key=lambda k: warm[k][0])
-    hs.set_profiling([dominant])
 
+    # The dominant kernel is timed with HIP events on the library's stream in one
+    # of every EVENT_STRIDE timed steps: event records serialise the queue for a
+    # few microseconds, which is visible at this frame length.
+    hs.set_profiling(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        sampled = k % EVENT_STRIDE == 0
+        if sampled:
+            hs.set_profiling([dominant])
         step()
+        if sampled:
+            hs.set_profiling(False)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -191,7 +200,7 @@ def main() -> int:
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "avg_launch_us": round(dom_avg_s * 1e6 / launches, 2),
-        "launches_per_step": launches,
+        "launches_per_step": launches, "event_samples": dom_n,
         "algorithmic_bytes_per_step": int(alg_bytes),
     }
     stage_us = {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in warm.items() if v[1]}

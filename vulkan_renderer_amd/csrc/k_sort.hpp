@@ -1,5 +1,4 @@
-// k_sort.hpp - stable LSD radix sort of the transparent draw keys in LDS, and
-// draw emission.
+// k_sort.hpp - ordering of the transparent draw keys and draw emission.
 //
 // Key: ((uint64)bits(depth) << 32) | (source_index + 1), depth clamped >= 0
 // (lib/src/application.h:573-587), ordered DESCENDING by the reference's
@@ -8,21 +7,19 @@
 // reference's order. The low word names the source row, so no payload travels
 // with the key.
 //
-// The visible blend rows arrive in ascending source index. A STABLE ascending
-// sort on key bits [begin_bit, 64) followed by reading the result backwards
-// therefore yields descending keys with larger source index first among equal
-// depths - exactly descending order on the full 64-bit key - while only the 32
-// depth bits have to be moved through the radix passes. A full 64-bit sort
-// (begin_bit = 0) is the same code with eight passes.
-//
-// Two paths, selected on the device from the element count (no host round
-// trip between cull and sort):
-//   count <= SMALL_KEYS  one workgroup keeps both key buffers in LDS and runs
-//                        every pass there (k_sort_small);
-//   larger               per 8-bit pass: per-tile digit histogram -> exclusive
-//                        scan over (digit, tile) -> stable scatter.
-// Ranking inside a wave is a 64-wide match on the digit built from eight
-// ballots, with per-wave running digit counters in LDS.
+// Small counts (<= RANK_LIMIT) are ordered by counting, in the same launch that
+// emits the rows (k_rank_emit). Larger counts go through a stable LSD radix
+// sort: the visible blend rows arrive in ascending source index, so a STABLE
+// ascending sort on key bits [32, 64) followed by reading the result backwards
+// yields descending keys with larger source index first among equal depths -
+// exactly descending order on the full 64-bit key - while only the 32 depth
+// bits have to be moved through the radix passes. Per 8-bit pass: per-tile
+// digit histogram -> exclusive scan over (digit, tile) -> stable scatter; a
+// single workgroup that keeps both key buffers in LDS (k_sort_small) takes over
+// when the count turns out to be small. All kernels read the count on the
+// device (no host round trip between cull and sort). Ranking inside a wave is a
+// 64-wide match on the digit built from eight ballots, with per-wave running
+// digit counters in LDS.
 #pragma once
 #include "device_math.hpp"
 #include "k_cull.hpp"
@@ -214,39 +211,22 @@ __device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *
   return true;
 }
 
-// Sort of keys[0, count) on bits [begin_shift, 64) by one workgroup, result in
-// `keys`. count <= SMALL_KEYS runs entirely in LDS. Larger counts are sorted
-// only when `any_count` is set (the host launched no multi-pass kernels because
-// it expected a small count): the same passes then stream through global memory
-// between `keys` and `scratch` - correct, but at one CU's bandwidth.
-__global__ __launch_bounds__(SMALL_THREADS) void k_sort_small(uint64_t *keys, uint64_t *scratch,
+// Sort of keys[0, count) on bits [begin_shift, 64) by one workgroup, entirely in
+// LDS, result in `keys`. Does nothing above SMALL_KEYS keys (the multi-pass
+// kernels launched next to it then do the work).
+__global__ __launch_bounds__(SMALL_THREADS) void k_sort_small(uint64_t *keys,
                                                               const uint32_t *counters,
-                                                              uint32_t begin_shift,
-                                                              uint32_t any_count) {
+                                                              uint32_t begin_shift) {
   __shared__ SmallSortShared s;
   const uint32_t count = counters[CNT_TRANSPARENT];
-  if (count == 0) return;
+  if (count == 0 || count > SMALL_KEYS) return;
   const uint32_t t = threadIdx.x;
-  if (count <= SMALL_KEYS) {
-    for (uint32_t k = t; k < count; k += SMALL_THREADS) s.keys[0][k] = keys[k];
-    uint32_t cur = 0;
-    for (uint32_t shift = begin_shift; shift < 64u; shift += 8u)
-      if (block_radix_pass(s.keys[cur], s.keys[cur ^ 1u], count, shift, s)) cur ^= 1u;
-    __syncthreads();
-    for (uint32_t k = t; k < count; k += SMALL_THREADS) keys[k] = s.keys[cur][k];
-  } else if (any_count) {
-    uint64_t *src = keys, *dst = scratch;
-    for (uint32_t shift = begin_shift; shift < 64u; shift += 8u) {
-      if (block_radix_pass(src, dst, count, shift, s)) {
-        uint64_t *tmp = src;
-        src = dst;
-        dst = tmp;
-      }
-    }
-    __syncthreads();
-    if (src != keys)
-      for (uint32_t k = t; k < count; k += SMALL_THREADS) keys[k] = src[k];
-  }
+  for (uint32_t k = t; k < count; k += SMALL_THREADS) s.keys[0][k] = keys[k];
+  uint32_t cur = 0;
+  for (uint32_t shift = begin_shift; shift < 64u; shift += 8u)
+    if (block_radix_pass(s.keys[cur], s.keys[cur ^ 1u], count, shift, s)) cur ^= 1u;
+  __syncthreads();
+  for (uint32_t k = t; k < count; k += SMALL_THREADS) keys[k] = s.keys[cur][k];
 }
 
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
@@ -369,45 +349,130 @@ __host__ __device__ __forceinline__ uint32_t encode_scene_object_id(uint32_t ren
   return render_id + 1u;
 }
 
-// vkr_transparent_draw_emit, lib/src/renderer/vkr_visibility.c:15-35. Eight
-// lanes per output row: lanes 0-2 write the three 16-byte pieces of the
-// VkrDrawItem, lanes 3-7 the five of the VkrInstanceDataGPU, so each output
-// array is written in consecutive 16-byte pieces.
+// One 16-byte piece of output row `row` (descending order) for sort key `key`:
+// vkr_transparent_draw_emit, lib/src/renderer/vkr_visibility.c:15-35. Pieces 0-2
+// are the VkrDrawItem, 3-7 the VkrInstanceDataGPU; eight lanes take one row so
+// that each output array is written in consecutive 16-byte pieces.
+__device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32_t row,
+                                                       uint64_t key, uint32_t piece) {
+  // the low word is source_index + 1 (application.h:657-658)
+  const uint32_t i = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
+  if (piece < 3u) {
+    uint4 o;
+    if (piece == 0u) {
+      o = a.ident[(uint64_t)i * 2u];  // mesh.id, mesh.generation, geometry.id, geometry.generation
+    } else if (piece == 1u) {
+      const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
+      o = make_uint4(id1.x, id1.y, id1.z, 1u);  // submesh_index, material, instance_count
+    } else {
+      o = make_uint4(row, 0u, (uint32_t)key, (uint32_t)(key >> 32));  // first_instance, pad, key
+      a.out_keys[row] = key;
+      a.out_source[row] = i;
+    }
+    a.draws[(uint64_t)row * 3u + piece] = o;
+  } else {
+    const uint32_t c = piece - 3u;
+    float4 o;
+    if (c < 4u) {
+      const uint64_t nd = a.node ? a.node[i] : i;
+      o = a.world[nd * 4u + c];
+    } else {
+      const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
+      o = make_float4(__uint_as_float(encode_scene_object_id(id1.w)), 0.f, 0.f, 0.f);
+    }
+    a.instances[(uint64_t)row * 5u + c] = o;
+  }
+}
+
+// Emission from the ascending-sorted key array, read backwards.
 __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   const uint32_t rows_per_block = 256u / 8u;
   const uint32_t piece = threadIdx.x & 7u;
   for (uint32_t row = blockIdx.x * rows_per_block + (threadIdx.x >> 3); row < count;
-       row += gridDim.x * rows_per_block) {
-    const uint32_t slot = count - 1u - row;  // read the ascending result backwards
-    const uint64_t key = a.keys[slot];
-    // the low word is source_index + 1 (application.h:657-658)
-    const uint32_t i = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
-    if (piece < 3u) {
-      uint4 o;
-      if (piece == 0u) {
-        o = a.ident[(uint64_t)i * 2u];  // mesh.id, mesh.generation, geometry.id, geometry.generation
-      } else if (piece == 1u) {
-        const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
-        o = make_uint4(id1.x, id1.y, id1.z, 1u);  // submesh_index, material, instance_count
-      } else {
-        o = make_uint4(row, 0u, (uint32_t)key, (uint32_t)(key >> 32));  // first_instance, pad, key
-        a.out_keys[row] = key;
-        a.out_source[row] = i;
+       row += gridDim.x * rows_per_block)
+    emit_transparent_piece(a, row, a.keys[count - 1u - row], piece);
+}
+
+// Sort + emission in one launch for small counts. Sort keys are unique (the low
+// word is the source row), so the output row of a key is simply the number of
+// keys greater than it. Every block stages the key array in LDS; a wave takes
+// RANK_WAVE_KEYS keys at a time and sweeps the whole array past them, 64 keys
+// per step, one compare + ballot population count per (key, step); its 64 lanes
+// then write the eight 16-byte pieces of the eight rows. count^2 / 64 compares:
+// 1M wave-steps at 8192 keys, spread over every CU that got a block, against
+// four passes of barriers and LDS atomics on one CU for a radix sort.
+//
+// Above RANK_LIMIT keys the quadratic sweep is not started: block 0 alone sorts
+// by streaming radix passes through global memory and emits every row. That
+// only happens when the host launched this kernel on a stale small estimate of
+// the count; it is correct, but runs at one CU's bandwidth.
+constexpr int RANK_WAVE_KEYS = 8;
+constexpr uint32_t RANK_LIMIT = SMALL_KEYS;
+
+__global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_t *keys,
+                                                             uint64_t *scratch) {
+  __shared__ SmallSortShared s;  // keys[0]: the staged key array; all of it: the fallback
+  const uint32_t count = a.counters[CNT_TRANSPARENT];
+  if (count == 0) return;
+  const uint32_t t = threadIdx.x;
+  if (count > RANK_LIMIT) {
+    if (blockIdx.x != 0) return;
+    uint64_t *src = keys, *dst = scratch;
+    for (uint32_t shift = 32u; shift < 64u; shift += 8u) {
+      if (block_radix_pass(src, dst, count, shift, s)) {
+        uint64_t *tmp = src;
+        src = dst;
+        dst = tmp;
       }
-      a.draws[(uint64_t)row * 3u + piece] = o;
-    } else {
-      const uint32_t c = piece - 3u;
-      float4 o;
-      if (c < 4u) {
-        const uint64_t nd = a.node ? a.node[i] : i;
-        o = a.world[nd * 4u + c];
-      } else {
-        const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
-        o = make_float4(__uint_as_float(encode_scene_object_id(id1.w)), 0.f, 0.f, 0.f);
-      }
-      a.instances[(uint64_t)row * 5u + c] = o;
     }
+    __syncthreads();
+    for (uint32_t row = t >> 3; row < count; row += SMALL_THREADS / 8u)
+      emit_transparent_piece(a, row, src[count - 1u - row], t & 7u);
+    return;
+  }
+
+  // every block keeps a copy of the key array in LDS: one round of coalesced
+  // loads instead of a global-memory round trip per sweep step
+  uint64_t *all = s.keys[0];
+  for (uint32_t k = t; k < count; k += SMALL_THREADS) all[k] = keys[k];
+  for (uint32_t k = count + t; k < ((count + 255u) & ~255u); k += SMALL_THREADS)
+    all[k] = 0ull;  // padding of the last sweep step; sort keys are >= 1
+  __syncthreads();
+
+  const uint32_t lane = t & 63u;
+  const uint32_t waves = gridDim.x * (SMALL_THREADS / 64u);
+  const uint32_t groups = (count + RANK_WAVE_KEYS - 1u) / RANK_WAVE_KEYS;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));  // keeps g scalar
+  for (uint32_t g = blockIdx.x * (SMALL_THREADS / 64u) + wave; g < groups; g += waves) {
+    // the wave's own keys, broadcast LDS reads; slots past the end repeat the
+    // last key (they are not emitted)
+    uint64_t mine[RANK_WAVE_KEYS];
+    uint32_t greater[RANK_WAVE_KEYS];
+#pragma unroll
+    for (int k = 0; k < RANK_WAVE_KEYS; ++k) {
+      const uint32_t i = g * RANK_WAVE_KEYS + (uint32_t)k;
+      mine[k] = all[min(i, count - 1u)];
+      greater[k] = 0u;
+    }
+    for (uint32_t base = 0; base < count; base += 256u) {
+      uint64_t other[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) other[u] = all[base + (uint32_t)u * 64u + lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < RANK_WAVE_KEYS; ++k)
+          greater[k] += (uint32_t)__popcll(__ballot(other[u] > mine[k]));
+    }
+    // lane = 8 * key slot + piece
+    const uint32_t slot = lane >> 3;
+    uint32_t row = 0u;
+#pragma unroll
+    for (int k = 0; k < RANK_WAVE_KEYS; ++k)
+      if (slot == (uint32_t)k) row = greater[k];
+    const uint32_t i = g * RANK_WAVE_KEYS + slot;
+    if (i < count) emit_transparent_piece(a, row, all[i], lane & 7u);
   }
 }
 

@@ -753,58 +753,69 @@ static int launch_compaction(vkrhip_ctx *c) {
   return VKRHIP_OK;
 }
 
+static EmitArgs emit_args(vkrhip_ctx *c) {
+  EmitArgs e{};
+  e.keys = c->keys_a.p;
+  e.counters = c->counters();
+  e.world = c->world.p;
+  e.node = c->node_identity ? nullptr : c->node.p;
+  e.ident = c->ident.p;
+  e.draws = c->draws.p;
+  e.instances = c->instances.p;
+  e.out_keys = c->out_keys.p;
+  e.out_source = c->out_source.p;
+  e.index_base = c->cfg.source_index_base;
+  return e;
+}
+
 static int launch_transparent(vkrhip_ctx *c) {
   const uint64_t cap = std::min<uint64_t>(c->tcap, std::max<uint64_t>(c->blend_rows, 1));
+  // The element count is only known on the device; the host has the static bound
+  // `cap` and the count the scan kernel reported for an earlier frame. When
+  // either says the count is small, one launch ranks every key against all
+  // others and emits the rows (k_rank_emit). Otherwise the multi-pass radix
+  // kernels run on the depth bits (the low word is already ordered by
+  // construction), next to a single-workgroup LDS sort that takes over when the
+  // count turns out small after all, and a separate emission launch follows.
+  // Every kernel re-checks the real count, so a wrong guess costs time, never
+  // correctness.
+  const uint32_t hint = *reinterpret_cast<volatile uint32_t *>(c->host_hint);
+  uint64_t expected = cap;
+  if (hint != 0u) expected = std::min<uint64_t>(cap, (uint64_t)(hint - 1u) * 5u / 4u + 256u);
+  if (expected <= RANK_LIMIT) {
+    StageTimer timer(c, VKRHIP_TIMER_SORT);
+    const unsigned grid = (unsigned)std::max<uint64_t>(
+        1, ceil_div(expected, (uint64_t)RANK_WAVE_KEYS * (SMALL_THREADS / 64)));
+    hipLaunchKernelGGL(k_rank_emit, dim3(grid), dim3(SMALL_THREADS), 0, c->stream, emit_args(c),
+                       c->keys_a.p, c->keys_b.p);
+    HIP_TRY(c, hipGetLastError());
+    return VKRHIP_OK;
+  }
   {
     StageTimer timer(c, VKRHIP_TIMER_SORT);
-    // Depth bits only: the low word is already ordered by construction. The
-    // element count is only known on the device. A single workgroup sorts
-    // count <= SMALL_KEYS in LDS; above that the multi-pass kernels do the work
-    // (and return at once below it). When the bound on the count is small, or
-    // the count the scan kernel reported for an earlier frame was comfortably
-    // small, the multi-pass kernels are not launched at all and the single
-    // workgroup is told to sort whatever it finds, so a wrong guess costs time,
-    // never correctness. After four passes the multi-pass result is back in
-    // keys_a too.
-    const uint32_t hint = *reinterpret_cast<volatile uint32_t *>(c->host_hint);
-    const bool expect_small =
-        cap <= SMALL_KEYS || (hint != 0u && (uint64_t)(hint - 1u) * 5u / 4u + 256u <= SMALL_KEYS);
     hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SMALL_THREADS), 0, c->stream, c->keys_a.p,
-                       c->keys_b.p, c->counters(), 32u, expect_small ? 1u : 0u);
-    if (!expect_small) {
-      const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
-      bool in_a = true;
-      for (uint32_t shift = 32; shift < 64; shift += 8) {
-        SortArgs s{};
-        s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
-        s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
-        s.hist = c->hist.p;
-        s.counters = c->counters();
-        s.tiles_stride = c->sort_tiles_stride;
-        s.shift = shift;
-        hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-        in_a = !in_a;
-      }
+                       c->counters(), 32u);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
+    bool in_a = true;
+    for (uint32_t shift = 32; shift < 64; shift += 8) {  // four passes end in keys_a again
+      SortArgs s{};
+      s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
+      s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
+      s.hist = c->hist.p;
+      s.counters = c->counters();
+      s.tiles_stride = c->sort_tiles_stride;
+      s.shift = shift;
+      hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
+      hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+      in_a = !in_a;
     }
     HIP_TRY(c, hipGetLastError());
   }
   {
     StageTimer timer(c, VKRHIP_TIMER_EMIT);
-    EmitArgs e{};
-    e.keys = c->keys_a.p;
-    e.counters = c->counters();
-    e.world = c->world.p;
-    e.node = c->node_identity ? nullptr : c->node.p;
-    e.ident = c->ident.p;
-    e.draws = c->draws.p;
-    e.instances = c->instances.p;
-    e.out_keys = c->out_keys.p;
-    e.out_source = c->out_source.p;
-    e.index_base = c->cfg.source_index_base;
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, 32), 4096);
-    hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, e);
+    hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, emit_args(c));
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
