@@ -14,9 +14,9 @@ frame:
 3. all-gather of the sorted draw-key runs, merged by the G-way rank merge kernel.
 
 The reference is single-GPU; nothing here has a counterpart in it. The
-collectives are plain torch.distributed calls, so the same code runs on `gloo`
-with CPU tensors in the tests (the two device kernels are then replaced by the
-caller, see tests/test_parallel_cpu.py).
+collectives are plain torch.distributed calls, so the same exchange runs on
+`gloo` with CPU tensors in the tests (the two device kernels are then served by
+a numpy-backed source, see tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
 
@@ -113,15 +113,57 @@ def wrap_device(ptr: int, count: int, dtype):
     return torch.as_tensor(_DevicePointer(ptr, count, typestr), device="cuda")
 
 
-class ShardExchange:
-    """Per-frame exchange of one rank's results with the other GPUs of the node."""
+class HipShardSource:
+    """What ShardExchange needs from one rank's scene, served from the HIP
+    library's device buffers (zero-copy torch views) and its two merge kernels."""
 
-    def __init__(self, scene, world: int, rank: int, views: int, group=None):
+    def __init__(self, scene):
         import torch
         self.torch = torch
         self.scene = scene
-        self.world, self.rank, self.views, self.group = world, rank, views, group
         self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def frame_info(self):
+        return self.scene.frame_info()  # waits for the frame; scalar results on the host
+
+    def begin(self):
+        self.out = self.scene.device_outputs()
+
+    def visible(self, view: int, count: int):
+        return wrap_device(self.out.visible + 4 * view * self.out.visible_stride, count,
+                           self.torch.int32)
+
+    def keys(self, count: int):
+        return wrap_device(self.out.transparent_keys, count, self.torch.int64)
+
+    def concat_ranges(self, gathered, merged, desc: np.ndarray):
+        self.scene.concat_ranges(gathered.data_ptr(), merged.data_ptr(), desc)
+
+    def merge_runs(self, gathered, run_stride: int, lengths: np.ndarray, merged):
+        ptrs = [gathered.data_ptr() + 8 * r * run_stride for r in range(lengths.shape[0])]
+        self.scene.merge_runs(ptrs, lengths, merged.data_ptr())
+
+
+class ShardExchange:
+    """Per-frame exchange of one rank's results with the other ranks.
+
+    `source` provides this rank's frame results and the two merge primitives
+    (HipShardSource on a GPU; the CPU tests pass a numpy-backed stand-in and run
+    the same exchange over `gloo`). After run(): vis_merged holds, view after
+    view, the merged visible list of every (view, bucket) (merged_ranges /
+    view_offsets describe it) and key_merged[:transparent_total] the merged
+    descending draw keys - identical on every rank.
+    """
+
+    def __init__(self, source, world: int, rank: int, views: int, group=None, device=None):
+        import torch
+        self.torch = torch
+        from .scene import HipScene
+        if isinstance(source, HipScene):
+            source = HipShardSource(source)
+        self.source = source
+        self.world, self.rank, self.views, self.group = world, rank, views, group
+        self.device = device if device is not None else source.device
         self.hdr_len = views * 8 + 2
         self.hdr_send = torch.zeros(self.hdr_len, dtype=torch.int64, device=self.device)
         self.hdr_recv = torch.zeros(world * self.hdr_len, dtype=torch.int64, device=self.device)
@@ -132,32 +174,33 @@ class ShardExchange:
         self.merged_ranges = None
         self.view_offsets = None
         self.transparent_total = 0
-        self.lib = N.load()
 
     def _grow(self, vis_need: int, key_need: int, merged_vis: int, merged_keys: int):
+        # every rank sees the same gathered header, so all ranks grow alike and the
+        # all-gather buffers keep equal sizes
         torch = self.torch
         if vis_need > self.vis_cap or self.vis_send is None:
             self.vis_cap = max(int(vis_need * 1.25) + 1024, 1024)
-            self.vis_send = torch.empty(self.vis_cap, dtype=torch.int32, device=self.device)
-            self.vis_recv = torch.empty(self.world * self.vis_cap, dtype=torch.int32, device=self.device)
+            self.vis_send = torch.zeros(self.vis_cap, dtype=torch.int32, device=self.device)
+            self.vis_recv = torch.zeros(self.world * self.vis_cap, dtype=torch.int32, device=self.device)
         if key_need > self.key_cap or self.key_send is None:
             self.key_cap = max(int(key_need * 1.25) + 1024, 1024)
-            self.key_send = torch.empty(self.key_cap, dtype=torch.int64, device=self.device)
-            self.key_recv = torch.empty(self.world * self.key_cap, dtype=torch.int64, device=self.device)
+            self.key_send = torch.zeros(self.key_cap, dtype=torch.int64, device=self.device)
+            self.key_recv = torch.zeros(self.world * self.key_cap, dtype=torch.int64, device=self.device)
         if self.vis_merged is None or self.vis_merged.numel() < merged_vis:
-            self.vis_merged = torch.empty(int(merged_vis * 1.25) + 1024, dtype=torch.int32,
+            self.vis_merged = torch.zeros(int(merged_vis * 1.25) + 1024, dtype=torch.int32,
                                           device=self.device)
         if self.key_merged is None or self.key_merged.numel() < merged_keys:
-            self.key_merged = torch.empty(int(merged_keys * 1.25) + 1024, dtype=torch.int64,
+            self.key_merged = torch.zeros(int(merged_keys * 1.25) + 1024, dtype=torch.int64,
                                           device=self.device)
 
     def run(self):
         torch, dist = self.torch, self.torch.distributed
-        hs, v, g = self.scene, self.views, self.world
-        info = hs.frame_info()      # waits for the frame; scalar results on the host
+        src, v, g = self.source, self.views, self.world
+        info = src.frame_info()
         hdr = np.zeros(self.hdr_len, np.int64)
         for vi, st in enumerate(info.views):
-            hdr[vi * 8: vi * 8 + 8] = st.execution_ranges.reshape(-1)
+            hdr[vi * 8: vi * 8 + 8] = np.asarray(st.execution_ranges).reshape(-1)
         hdr[v * 8] = info.transparent_draw_count
         self.hdr_send.copy_(torch.from_numpy(hdr))
         dist.all_gather_into_tensor(self.hdr_recv, self.hdr_send, group=self.group)
@@ -168,31 +211,27 @@ class ShardExchange:
         desc, merged_ranges, view_offsets, _ = plan_visible_merge(ranges)
         self._grow(int(vis_counts.max()), int(t_all.max()), int(view_offsets[-1]), int(t_all.sum()))
 
-        out = hs.device_outputs()
+        src.begin()
         # pack this rank's views back to back
         pos = 0
         for vi, st in enumerate(info.views):
-            cnt = st.visible_count
+            cnt = int(st.visible_count)
             if cnt:
-                src = wrap_device(out.visible + 4 * vi * out.visible_stride, cnt, torch.int32)
-                self.vis_send[pos: pos + cnt].copy_(src, non_blocking=True)
+                self.vis_send[pos: pos + cnt].copy_(src.visible(vi, cnt), non_blocking=True)
             pos += cnt
         dist.all_gather_into_tensor(self.vis_recv, self.vis_send, group=self.group)
-        t_local = info.transparent_draw_count
+        t_local = int(info.transparent_draw_count)
         if t_local:
-            self.key_send[:t_local].copy_(wrap_device(out.transparent_keys, t_local, torch.int64),
-                                          non_blocking=True)
+            self.key_send[:t_local].copy_(src.keys(t_local), non_blocking=True)
         dist.all_gather_into_tensor(self.key_recv, self.key_send, group=self.group)
 
-        # merged visible lists: one segmented copy
-        desc_dev = desc.copy()
-        per_vb = g
-        for k in range(desc_dev.shape[0]):
-            desc_dev[k, 0] += np.uint64((k % per_vb) * self.vis_cap)
-        hs.concat_ranges(self.vis_recv.data_ptr(), self.vis_merged.data_ptr(), desc_dev)
+        # merged visible lists: one segmented copy; descriptor k of a (view, bucket)
+        # belongs to rank k % g, whose packed list starts at rank * vis_cap
+        desc_abs = desc.copy()
+        desc_abs[:, 0] += (np.arange(desc.shape[0], dtype=np.uint64) % np.uint64(g)) * np.uint64(self.vis_cap)
+        src.concat_ranges(self.vis_recv, self.vis_merged, desc_abs)
         # merged draw keys: G-way merge of the descending runs
-        run_ptrs = [self.key_recv.data_ptr() + 8 * r * self.key_cap for r in range(g)]
-        hs.merge_runs(run_ptrs, t_all, self.key_merged.data_ptr())
+        src.merge_runs(self.key_recv, self.key_cap, t_all, self.key_merged)
         self.merged_ranges, self.view_offsets = merged_ranges, view_offsets
         self.transparent_total = int(t_all.sum())
         return self
