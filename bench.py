@@ -65,6 +65,27 @@ KERNEL_NAMES = {"transform": "k_propagate_level", "classify": "k_classify",
                 "fused": "k_propagate_classify"}
 
 
+def pmc_traffic(workload_name: str, overridden: bool, kernel: str):
+    """HBM bytes per step of the dominant kernel from the committed rocprofv3
+    counter passes of this workload (FETCH_SIZE doubled, the gfx950 correction
+    for wide coalesced reads, plus WRITE_SIZE; tools/pmc_passes.sh collects them
+    in separate runs). None when no pass of this exact workload is committed."""
+    if overridden:
+        return None, None
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload_name}.json")))
+    if not paths:
+        return None, None
+    with open(paths[-1]) as fh:
+        data = json.load(fh)
+    total = 0.0
+    for name, k in data["kernels"].items():
+        if name.startswith(kernel):
+            total += k["dispatches_per_frame"] * (k["fetch_bytes_per_dispatch_x2"] +
+                                                  k["write_bytes_per_dispatch"])
+    return (total or None), os.path.relpath(paths[-1], ROOT)
+
+
 def build_scene(workload: dict, rank: int, seed: int):
     from vulkan_renderer_amd import synth
     n = workload["n"]
@@ -195,10 +216,13 @@ def main() -> int:
     launches = 1 if dominant == "classify" else len(sc.level_offsets) - 1
     alg_bytes = kernel_bytes(dominant, n, workload["depth"], views)
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    overridden = bool(args.instances) or any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes"))
+    traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant])
     roofline = {
         "bound": "hbm", "kernel": KERNEL_NAMES[dominant],
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_source,
         "avg_launch_us": round(dom_avg_s * 1e6 / launches, 2),
         "launches_per_step": launches, "event_samples": dom_n,
         "algorithmic_bytes_per_step": int(alg_bytes),

@@ -225,8 +225,9 @@ int vkrhip_get_timers(vkrhip_ctx *ctx, double *ms_out, uint64_t *samples_out, in
 
 /* ---- multi-GPU draw-key merge (no reference counterpart: the reference is
  * single-GPU; this is the exchange step after an all-gather of per-GPU runs) --
- * runs_keys/runs_src: `g` device arrays, each sorted descending; lengths on the
- * host. Writes the merged descending keys and (rank,source) pairs. */
+ * runs_keys: `g` device arrays of sort keys, each sorted descending; lengths on
+ * the host. Writes the merged descending keys (the low key word names the
+ * source row, so no payload travels). */
 int vkrhip_merge_runs(vkrhip_ctx *ctx, uint32_t g, const uint64_t *const *runs_keys,
                       const uint64_t *lengths, uint64_t *out_keys_dev);
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Hardware-counter passes over one bench.py configuration, one rocprofv3 run per
-# counter group (the SQ and TCC blocks cannot hold more in a single run).
+# counter group (the SQ and TCC blocks cannot hold more in a single run). Each pass
+# runs 1 warm-up + 3 timed frames = 4 frames of the full path.
 #   tools/pmc_passes.sh <out-dir> <bench.py arguments...>
 set -e
 OUT=$1; shift
@@ -18,5 +19,5 @@ run_pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE
 run_pass sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT" > "$ROOT/$OUT/summary.txt"
+python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT" 4 "$ROOT/$OUT/traffic.json" > "$ROOT/$OUT/summary.txt"
 cat "$ROOT/$OUT/summary.txt"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 counter-collection CSVs per kernel and counter.
 
-    tools/pmc_summary.py <dir with one sub-directory per pass>
+    tools/pmc_summary.py <dir with one sub-directory per pass> [<frames> <traffic.json>]
 
 Prints, per kernel, the number of dispatches seen and the mean value per
 dispatch of every counter. FETCH_SIZE / WRITE_SIZE are reported in bytes
@@ -44,6 +44,21 @@ def main() -> int:
                 print(f"  {c:24s} n={n:5d} mean={b:.6g} B{extra}")
             else:
                 print(f"  {c:24s} n={n:5d} mean={mean:.6g}")
+    if len(sys.argv) > 3:  # <frames> <json path>: HBM traffic per kernel for bench.py
+        import json
+        frames = int(sys.argv[2])
+        out = {"frames": frames, "kernels": {}}
+        for k in acc:
+            if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+                f_total, f_n = acc[k]["FETCH_SIZE"]
+                w_total, w_n = acc[k]["WRITE_SIZE"]
+                out["kernels"][k] = {
+                    "dispatches_per_frame": f_n / frames,
+                    "fetch_bytes_per_dispatch_x2": 2 * 1024.0 * f_total / max(f_n, 1),
+                    "write_bytes_per_dispatch": 1024.0 * w_total / max(w_n, 1),
+                }
+        with open(sys.argv[3], "w") as fh:
+            json.dump(out, fh, indent=1)
     return 0
 
 
