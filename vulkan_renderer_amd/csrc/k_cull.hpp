@@ -16,9 +16,10 @@
 //               survivor counts per (view, bucket) row. It exists stand-alone
 //               (k_classify) and fused behind the transform of the same node
 //               (k_fused.hpp).
-//   k_scan      exclusive scan of the tile counts of every row, then the
-//               4-bucket prefix of vk_gpu_draw_prefix per view.
-//   k_scatter   re-reads the bit masks (not the matrices) and writes candidate
+//   k_scan      exclusive scan of the tile counts of every row (one block per
+//               row) and the row totals.
+//   k_scatter   4-bucket prefix of vk_gpu_draw_prefix per view from the row
+//               totals; re-reads the bit masks (not the matrices) and writes candidate
 //               indices at tile base + wave-ballot rank. Order inside a bucket
 //               is ascending candidate index, one of the orders the
 //               reference's atomics can produce.
@@ -399,87 +400,102 @@ __device__ __forceinline__ uint4 block_exclusive_scan4(uint4 v, uint4 *s_wave4, 
 
 struct ScanArgs {
   uint32_t *tile_counts;  // [row][tiles_stride], scanned in place
-  CompactionState *states;
+  uint32_t *row_totals;   // [rows]: survivors per (view, bucket) row and of the transparent row
   uint32_t *counters;
   uint64_t tiles;  // tiles in use this frame
   uint64_t tiles_stride;
   uint32_t views;
-  uint32_t partition_capacity;  // 0 = unlimited
-  uint64_t visible_capacity;
   uint64_t transparent_capacity;
-  uint32_t *host_hint;  // pinned host word: last frame's transparent count (may be null)
+  uint32_t *host_hint;   // pinned host word: last frame's transparent count (may be null)
+  uint32_t *clear;       // the NEXT frame's counter block, zeroed here (may be null)
+  uint32_t clear_words;
 };
 
-// One block per view (vk_gpu_draw_prefix, deferred.slang:354-377) plus one for
-// the transparent row.
+__device__ __forceinline__ uint32_t sum4(uint4 v) { return v.x + v.y + v.z + v.w; }
+
+// Exclusive scan of the tile counts, one 1024-thread block per row. A wave owns a
+// contiguous run of the row and reads it 64 x 16 bytes at a time (coalesced);
+// sweep 1 only totals each wave's run, one barrier combines the 16 totals, and
+// sweep 2 re-reads the run (from cache), scans it 64 uint4 at a time with wave
+// shuffles and writes the exclusive prefix in place: two memory round trips for
+// any tile count. Rows are padded with zeros to whole uint4s.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
-  __shared__ uint4 s_wave4[SCAN_BLOCK / 64];
   __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
-  const uint32_t v = blockIdx.x;
-  if (v < a.views) {
-    uint32_t *r0 = a.tile_counts + (uint64_t)(v * 4u + 0u) * a.tiles_stride;
-    uint32_t *r1 = a.tile_counts + (uint64_t)(v * 4u + 1u) * a.tiles_stride;
-    uint32_t *r2 = a.tile_counts + (uint64_t)(v * 4u + 2u) * a.tiles_stride;
-    uint32_t *r3 = a.tile_counts + (uint64_t)(v * 4u + 3u) * a.tiles_stride;
-    uint4 carry = make_uint4(0, 0, 0, 0);
-    for (uint64_t base = 0; base < a.tiles; base += SCAN_BLOCK) {
-      const uint64_t k = base + threadIdx.x;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (k < a.tiles) val = make_uint4(r0[k], r1[k], r2[k], r3[k]);
-      uint4 total;
-      const uint4 ex = block_exclusive_scan4(val, s_wave4, &total);
-      if (k < a.tiles) {
-        r0[k] = carry.x + ex.x;
-        r1[k] = carry.y + ex.y;
-        r2[k] = carry.z + ex.z;
-        r3[k] = carry.w + ex.w;
-      }
-      carry.x += total.x;
-      carry.y += total.y;
-      carry.z += total.z;
-      carry.w += total.w;
-    }
-    if (threadIdx.x == 0) {
-      const uint32_t counts[4] = {carry.x, carry.y, carry.z, carry.w};
-      CompactionState st;
-      uint32_t cursor = 0, overflow = 0;
-      const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
-      for (uint32_t b = 0; b < 4u; ++b) {
-        const uint32_t count = counts[b];
-        const uint32_t written = count < cap ? count : cap;
-        st.execution_ranges[b][0] = cursor;
-        st.execution_ranges[b][1] = written;
-        st.bucket_counts[b] = count;
-        // every surviving thread of vk_gpu_draw_encode bumps the cursor once
-        st.bucket_cursors[b] = count;
-        cursor += written;
-        overflow += count - written;
-      }
-      st.visible_count = cursor;
-      st.overflow_count = overflow;
-      st.resolve_invalid_count = 0;
-      st.occlusion_culled_count = 0;
-      a.states[v] = st;
-    }
-  } else {
-    uint32_t *row = a.tile_counts + (uint64_t)(a.views * 4u) * a.tiles_stride;
-    uint32_t carry = 0;
-    for (uint64_t base = 0; base < a.tiles; base += SCAN_BLOCK) {
-      const uint64_t k = base + threadIdx.x;
-      const uint32_t val = k < a.tiles ? row[k] : 0u;
-      uint32_t total;
-      const uint32_t ex = block_exclusive_scan(val, s_wave, &total);
-      if (k < a.tiles) row[k] = carry + ex;
-      carry += total;
-    }
-    if (threadIdx.x == 0) {
+  const uint32_t r = blockIdx.x;
+  uint4 *row = reinterpret_cast<uint4 *>(a.tile_counts + (uint64_t)r * a.tiles_stride);
+  const uint64_t quads = (a.tiles + 3u) / 4u;
+  const uint32_t w = threadIdx.x >> 6;
+  const uint32_t lane = lane_id();
+  const uint64_t wave_quads = ((quads + SCAN_BLOCK / 64 - 1) / (SCAN_BLOCK / 64) + 63u) & ~(uint64_t)63u;
+  const uint64_t qb = min((uint64_t)w * wave_quads, quads);
+  const uint64_t qe = min(qb + wave_quads, quads);
+
+  uint32_t mine = 0u;
+  for (uint64_t q = qb + lane; q < qe; q += 64u) mine += sum4(row[q]);
+  const uint32_t wave_total = (uint32_t)__shfl((int)wave_inclusive_scan(mine), 63, 64);
+  if (lane == 0) s_wave[w] = wave_total;
+  __syncthreads();
+  uint32_t carry = 0u, total = 0u;
+  for (uint32_t k = 0; k < SCAN_BLOCK / 64; ++k) {
+    const uint32_t x = s_wave[k];
+    if (k < w) carry += x;
+    total += x;
+  }
+  for (uint64_t q0 = qb; q0 < qe; q0 += 64u) {  // wave-uniform trip count
+    const uint64_t q = q0 + lane;
+    const bool valid = q < qe;
+    const uint4 v = valid ? row[q] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t s = sum4(v);
+    const uint32_t incl = wave_inclusive_scan(s);
+    uint4 o;
+    o.x = carry + incl - s;
+    o.y = o.x + v.x;
+    o.z = o.y + v.y;
+    o.w = o.z + v.z;
+    // the padding of the last uint4 stays zero: it may be a real tile next frame
+    if (q * 4u + 1u >= a.tiles) o.y = 0u;
+    if (q * 4u + 2u >= a.tiles) o.z = 0u;
+    if (q * 4u + 3u >= a.tiles) o.w = 0u;
+    if (valid) row[q] = o;
+    carry += (uint32_t)__shfl((int)incl, 63, 64);
+  }
+  if (r == 0 && a.clear != nullptr)
+    for (uint32_t k = threadIdx.x; k < a.clear_words; k += SCAN_BLOCK) a.clear[k] = 0u;
+  if (threadIdx.x == 0) {
+    a.row_totals[r] = total;
+    if (r == a.views * 4u) {  // the transparent row
       const uint64_t cap = a.transparent_capacity;
-      a.counters[CNT_TRANSPARENT_TOTAL] = carry;
-      a.counters[CNT_TRANSPARENT] = (uint64_t)carry < cap ? carry : (uint32_t)cap;
+      a.counters[CNT_TRANSPARENT_TOTAL] = total;
+      a.counters[CNT_TRANSPARENT] = (uint64_t)total < cap ? total : (uint32_t)cap;
       // lets the host pick the sort path of later frames without waiting
-      if (a.host_hint) *reinterpret_cast<volatile uint32_t *>(a.host_hint) = carry + 1u;
+      if (a.host_hint) *reinterpret_cast<volatile uint32_t *>(a.host_hint) = total + 1u;
     }
   }
+}
+
+// vk_gpu_draw_prefix (deferred.slang:354-377): the four bucket totals of a view
+// become execution ranges clamped to the partition capacity.
+__device__ __forceinline__ CompactionState prefix_state(const uint32_t *totals4,
+                                                        uint32_t partition_capacity) {
+  CompactionState st;
+  uint32_t cursor = 0, overflow = 0;
+  const uint32_t cap = partition_capacity ? partition_capacity : 0xffffffffu;
+  for (uint32_t b = 0; b < 4u; ++b) {
+    const uint32_t count = totals4[b];
+    const uint32_t written = count < cap ? count : cap;
+    st.execution_ranges[b][0] = cursor;
+    st.execution_ranges[b][1] = written;
+    st.bucket_counts[b] = count;
+    // every surviving thread of vk_gpu_draw_encode bumps the cursor once
+    st.bucket_cursors[b] = count;
+    cursor += written;
+    overflow += count - written;
+  }
+  st.visible_count = cursor;
+  st.overflow_count = overflow;
+  st.resolve_invalid_count = 0;
+  st.occlusion_culled_count = 0;
+  return st;
 }
 
 struct ScatterArgs {
@@ -487,8 +503,9 @@ struct ScatterArgs {
   const uint32_t *cflags;
   const uint8_t *tvis;
   const uint64_t *tkey;
-  const uint32_t *tile_offsets;  // scanned tile counts
-  const CompactionState *states;
+  uint32_t *tile_offsets;        // scanned tile counts; zeroed again once consumed
+  const uint32_t *row_totals;    // from k_scan
+  CompactionState *states;       // written by block 0
   uint32_t *visible;  // [view][visible_stride]
   uint64_t *keys;     // compacted sort keys of the visible blend rows
   uint64_t n;
@@ -559,14 +576,22 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
   // of the tile's scanned offset
   for (uint32_t r = t; r < rows; r += CULL_BLOCK) {
     uint32_t run = a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
+    a.tile_offsets[(uint64_t)r * a.tiles_stride + tile] = 0u;  // ready for the next frame's counts
 #pragma unroll
     for (int slot = 0; slot < CULL_ROUNDS * 4; ++slot) {
       const uint32_t c = s_cnt[slot][r];
       s_cnt[slot][r] = run;
       run += c;
     }
-    s_range[r] = r < a.views * 4u ? a.states[r >> 2].execution_ranges[r & 3u][0] : 0u;
+    // start of the row's bucket inside its view: the clamped totals of the buckets before it
+    uint32_t range = 0u;
+    if (r < a.views * 4u)
+      for (uint32_t b = 0; b < (r & 3u); ++b) range += min(a.row_totals[(r & ~3u) + b], cap);
+    s_range[r] = range;
   }
+  if (blockIdx.x == 0)
+    for (uint32_t v = t; v < a.views; v += CULL_BLOCK)
+      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity);
   __syncthreads();
 
   // phase 2: positions

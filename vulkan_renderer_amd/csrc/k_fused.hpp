@@ -9,9 +9,10 @@
 // (+ parent index 4 B below the root level).
 //
 // A block owns one 1024-node count tile (aligned to 1024 in the global node
-// index) and walks it in four rounds of 256 nodes. The loads of round r+1 are
-// issued before round r is consumed, so a block always has a round's worth of
-// HBM requests in flight while it computes.
+// index) and walks it in four rounds of 256 nodes (small levels: half or a
+// quarter of a tile). The matrices of round r+1 and the flags / cull inputs of
+// round r+2 are requested before round r is consumed, so a block always has
+// more than a round's worth of HBM requests in flight while it computes.
 //
 // Thread mapping inside a round:
 //   transform phase  4 lanes per node, lane j owns column j, four sub-rounds of
@@ -37,7 +38,8 @@ constexpr int FUSED_WINDOW = 128;                      // LDS-staged parent wind
 
 struct FusedArgs {
   TransformArgs t;
-  CullArgs c;  // c.n = candidates; candidate i <-> node i
+  CullArgs c;       // c.n = candidates; candidate i <-> node i
+  uint32_t rounds;  // rounds of a tile one block walks: 4, 2 or 1 (more, shorter blocks)
 };
 
 // min and max of `p` over the lanes of the wave that hold a parent index
@@ -161,11 +163,18 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
 
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
-  const uint64_t tile = a.t.begin / CULL_TILE + blockIdx.x;
+  // Small levels are cut into more blocks of fewer rounds: a lone block per CU
+  // cannot hide its own load latency.
+  const uint32_t per_tile = (uint32_t)FUSED_ROUNDS / a.rounds;
+  const uint64_t tile = a.t.begin / CULL_TILE + blockIdx.x / per_tile;
   const uint64_t tile_base = tile * CULL_TILE;
-  // the level's part of this tile, as offsets into the tile (lo < hi by the grid size)
-  const uint32_t lo = a.t.begin > tile_base ? (uint32_t)(a.t.begin - tile_base) : 0u;
-  const uint32_t hi = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tile_base);
+  const uint32_t first_round = (blockIdx.x % per_tile) * a.rounds;
+  // the block's part of the level, as offsets into the tile
+  uint32_t lo = a.t.begin > tile_base ? (uint32_t)(a.t.begin - tile_base) : 0u;
+  uint32_t hi = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tile_base);
+  lo = max(lo, first_round * FUSED_BLOCK);
+  hi = min(hi, (first_round + a.rounds) * FUSED_BLOCK);
+  if (lo >= hi) return;  // block-uniform
   if (t == 0) s_updated = 0u;
   cull_shared_clear(s, a.c.views);
 

@@ -250,28 +250,31 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
   }
 }
 
-// Exclusive scan over hist[digit][0..tiles) in digit-major order, one block.
+// Exclusive scan over hist[digit][0..tiles) in digit-major order, one block:
+// four threads per digit, each owning a quarter of the digit's tile row. A
+// thread sums its run, one block-wide scan of the 1024 sums gives its starting
+// offset, and a second sweep writes the exclusive prefix in place.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_radix_scan(SortArgs a) {
+  static_assert(SCAN_BLOCK == SORT_RADIX * 4, "four threads per digit");
   __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
-  const uint64_t total_entries = (uint64_t)SORT_RADIX * tiles;
-  uint32_t carry = 0;
-  for (uint64_t base = 0; base < total_entries; base += SCAN_BLOCK) {
-    const uint64_t e = base + threadIdx.x;
-    uint32_t v = 0;
-    uint64_t addr = 0;
-    if (e < total_entries) {
-      const uint32_t digit = (uint32_t)(e / tiles);
-      const uint32_t tile = (uint32_t)(e - (uint64_t)digit * tiles);
-      addr = (uint64_t)digit * a.tiles_stride + tile;
-      v = a.hist[addr];
-    }
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan(v, s_wave, &total);
-    if (e < total_entries) a.hist[addr] = carry + ex;
-    carry += total;
+  const uint32_t digit = threadIdx.x >> 2, part = threadIdx.x & 3u;
+  const uint32_t chunk = (tiles + 3u) / 4u;
+  const uint32_t begin = min(part * chunk, tiles);
+  const uint32_t end = min(begin + chunk, tiles);
+  uint32_t *row = a.hist + (uint64_t)digit * a.tiles_stride;
+  uint32_t sum = 0u;
+#pragma unroll 8
+  for (uint32_t k = begin; k < end; ++k) sum += row[k];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(sum, s_wave, &total);
+#pragma unroll 8
+  for (uint32_t k = begin; k < end; ++k) {
+    const uint32_t c = row[k];
+    row[k] = run;
+    run += c;
   }
 }
 

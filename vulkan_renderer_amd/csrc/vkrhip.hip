@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,6 +57,7 @@ struct vkrhip_ctx {
   DevBuf<float4> local, world;
   DevBuf<uint8_t> flags;
   uint32_t force_flags = 0;
+  uint32_t fused_rounds = 0;  // tuning override (VKRHIP_FUSED_ROUNDS = 1, 2 or 4); 0 = by level size
   bool have_trs = false;
 
   // candidates
@@ -81,18 +83,29 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> masks;
   DevBuf<uint8_t> tvis;
   DevBuf<CompactionState> states;
-  // zeroed by one fill per frame: [counters | tie counters | tile counts]
+  DevBuf<uint32_t> row_totals;  // survivors per count row, written by k_scan
+  // Per-frame accumulators: [counter block 0 | counter block 1 | tile counts], a
+  // counter block being [sharded counters | tie counters]. Frames alternate
+  // between the two counter blocks. The compaction kernels of a frame zero the
+  // other block and the tile counts they have consumed, so steady-state frames
+  // start without a fill; the flags below fall back to a fill whenever a frame
+  // ran without those kernels.
   DevBuf<uint8_t> frame_zero;
+  uint32_t cur_block = 0;
+  bool block_clean[2] = {true, true};
+  bool tiles_clean = true;
   static constexpr size_t kCountersBytes = sizeof(uint32_t) * CNT_COUNT * STAT_SHARDS;
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
-  size_t zero_header_bytes() const { return kCountersBytes + kTiesBytes; }
-  uint32_t *counters() const { return reinterpret_cast<uint32_t *>(frame_zero.p); }
+  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes;
+  uint8_t *counter_block(uint32_t i) const { return frame_zero.p + (size_t)i * kBlockBytes; }
+  uint32_t *counters() const { return reinterpret_cast<uint32_t *>(counter_block(cur_block)); }
   unsigned long long *ties() const {
-    return reinterpret_cast<unsigned long long *>(frame_zero.p + kCountersBytes);
+    return reinterpret_cast<unsigned long long *>(counter_block(cur_block) + kCountersBytes);
   }
   uint32_t *tile_counts() const {
-    return reinterpret_cast<uint32_t *>(frame_zero.p + kCountersBytes + kTiesBytes);
+    return reinterpret_cast<uint32_t *>(frame_zero.p + 2u * kBlockBytes);
   }
+  size_t tile_counts_bytes() const { return frame_zero.count - 2u * kBlockBytes; }
   DevBuf<uint64_t> tkey;
   DevBuf<uint32_t> visible;
   uint64_t visible_stride = 0;
@@ -259,6 +272,10 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   c->cfg = *config;
   c->device = config->device;
   if (c->cfg.visible_capacity == 0) c->cfg.visible_capacity = c->cfg.max_candidates;
+  if (const char *env = std::getenv("VKRHIP_FUSED_ROUNDS")) {
+    const int r = std::atoi(env);
+    if (r == 1 || r == 2 || r == 4) c->fused_rounds = (uint32_t)r;
+  }
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
@@ -280,15 +297,16 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->camera_view, 4));
     c->mask_words = (c->cfg.max_views + 31u) / 32u;
-    c->tiles_stride = ceil_div(mc, CULL_TILE);
+    c->tiles_stride = (ceil_div(mc, CULL_TILE) + 3u) & ~(uint64_t)3u;  // rows are whole uint4s
     TRY(dev_alloc(c, c->masks, (size_t)c->mask_words * mc));
     TRY(dev_alloc(c, c->tvis, mc));
     TRY(dev_alloc(c, c->frame_zero,
-                  c->zero_header_bytes() +
+                  2u * vkrhip_ctx::kBlockBytes +
                       (size_t)(c->cfg.max_views * 4u + 1u) * c->tiles_stride * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, c->frame_zero.count, c->stream));
     TRY(dev_alloc(c, c->tkey, mc));
     TRY(dev_alloc(c, c->states, VKRHIP_MAX_VIEWS));
+    TRY(dev_alloc(c, c->row_totals, CULL_MAX_ROWS));
     HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
     HIP_TRY(c, hipHostMalloc((void **)&c->host_hint, 64, hipHostMallocMapped));
     c->host_hint[0] = 0u;
@@ -339,6 +357,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->frame_zero);
   dev_free(c->tkey);
   dev_free(c->states);
+  dev_free(c->row_totals);
   dev_free(c->visible);
   dev_free(c->world_bounds);
   dev_free(c->cand_rows);
@@ -659,6 +678,7 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
 // Transform and classify in one launch per level (candidate i <-> node i).
 static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
   StageTimer timer(c, VKRHIP_TIMER_FUSED);
+  c->tiles_clean = false;
   const uint32_t levels = (uint32_t)c->level_offsets.size() - 1u;
   const bool ties = c->cfg.tie_epsilon > 0.f;
   for (uint32_t l = 0; l < levels; ++l) {
@@ -666,8 +686,10 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.t = transform_args(c, l);
     a.c = cull_args(c);
     if (a.t.end == a.t.begin) continue;
-    const unsigned grid =
-        (unsigned)(ceil_div(a.t.end, CULL_TILE) - a.t.begin / CULL_TILE);
+    const uint64_t tiles = ceil_div(a.t.end, CULL_TILE) - a.t.begin / CULL_TILE;
+    // enough blocks to give every CU several: whole tiles only for large levels
+    a.rounds = c->fused_rounds ? c->fused_rounds : (tiles >= 1024 ? 4u : tiles >= 512 ? 2u : 1u);
+    const unsigned grid = (unsigned)(tiles * (FUSED_ROUNDS / a.rounds));
     if (l == 0 || !c->parent.p)
       launch_fused_variant<false>(c, a, grid, ties, bounds_out);
     else
@@ -699,6 +721,7 @@ static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
   if (!c->n_cand) return VKRHIP_OK;
   StageTimer timer(c, VKRHIP_TIMER_CLASSIFY);
   const CullArgs a = cull_args(c);
+  c->tiles_clean = false;
   const unsigned grid = (unsigned)ceil_div(c->n_cand, CULL_BLOCK);
   const bool ties = c->cfg.tie_epsilon > 0.f;
   if (c->node_identity)
@@ -712,21 +735,26 @@ static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
 static int launch_compaction(vkrhip_ctx *c) {
   const uint64_t n = c->n_cand;
   const uint64_t tiles = ceil_div(n, CULL_TILE);
+  if (!tiles) {  // nothing to compact: empty states, zero transparent rows (counters are zeroed)
+    HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
+    return VKRHIP_OK;
+  }
   {
     StageTimer timer(c, VKRHIP_TIMER_SCAN);
     ScanArgs s{};
     s.tile_counts = c->tile_counts();
-    s.states = c->states.p;
+    s.row_totals = c->row_totals.p;
     s.counters = c->counters();
     s.tiles = tiles;
     s.tiles_stride = c->tiles_stride;
     s.views = c->views;
-    s.partition_capacity = c->cfg.partition_capacity;
-    s.visible_capacity = c->visible_stride;
     s.transparent_capacity = c->tcap;
     s.host_hint = c->host_hint;
-    hipLaunchKernelGGL(k_scan, dim3(c->views + 1u), dim3(SCAN_BLOCK), 0, c->stream, s);
+    s.clear = reinterpret_cast<uint32_t *>(c->counter_block(c->cur_block ^ 1u));
+    s.clear_words = (uint32_t)(vkrhip_ctx::kBlockBytes / sizeof(uint32_t));
+    hipLaunchKernelGGL(k_scan, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, c->stream, s);
     HIP_TRY(c, hipGetLastError());
+    c->block_clean[c->cur_block ^ 1u] = true;
   }
   if (tiles) {
     StageTimer timer(c, VKRHIP_TIMER_SCATTER);
@@ -736,6 +764,7 @@ static int launch_compaction(vkrhip_ctx *c) {
     s.tvis = c->tvis.p;
     s.tkey = c->tkey.p;
     s.tile_offsets = c->tile_counts();
+    s.row_totals = c->row_totals.p;
     s.states = c->states.p;
     s.visible = c->visible.p;
     s.keys = c->keys_a.p;
@@ -749,6 +778,7 @@ static int launch_compaction(vkrhip_ctx *c) {
     s.partition_capacity = c->cfg.partition_capacity;
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)tiles), dim3(CULL_BLOCK), 0, c->stream, s);
     HIP_TRY(c, hipGetLastError());
+    c->tiles_clean = true;  // every count this frame produced has been consumed and zeroed
   }
   return VKRHIP_OK;
 }
@@ -858,13 +888,16 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
   if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
   {
     StageTimer frame_timer(c, VKRHIP_TIMER_FRAME);
-    // one fill zeroes the counters, the tie counters and the tile counts in use
-    const uint64_t tiles = ceil_div(c->n_cand, CULL_TILE);
-    const size_t zero_bytes =
-        cull ? c->zero_header_bytes() +
-                   ((size_t)(c->views * 4u) * c->tiles_stride + tiles) * sizeof(uint32_t)
-             : c->zero_header_bytes();
-    HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, zero_bytes, c->stream));
+    // this frame's counter block and the tile counts are normally already zero
+    // (cleared by the previous frame's compaction kernels)
+    c->cur_block ^= 1u;
+    if (!c->block_clean[c->cur_block])
+      HIP_TRY(c, hipMemsetAsync(c->counter_block(c->cur_block), 0, vkrhip_ctx::kBlockBytes, c->stream));
+    c->block_clean[c->cur_block] = false;
+    if (cull && !c->tiles_clean) {
+      HIP_TRY(c, hipMemsetAsync(c->tile_counts(), 0, c->tile_counts_bytes(), c->stream));
+      c->tiles_clean = true;
+    }
     // the fused kernel serves scenes that draw node i with candidate i
     const bool fused = cull && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
                        c->n_cand > 0 && c->n_cand <= c->n_nodes && c->level_offsets.size() > 1;
