@@ -532,17 +532,34 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
   const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
   const uint32_t words = (a.views + 31u) >> 5;
 
-  // all four rounds' inputs are requested up front
+  // All inputs are requested up front with unconditional loads from clamped
+  // indices (a select on a loaded value would become a branch around the load
+  // that waits for it); out-of-range lanes are blanked with integer masks.
+  const uint64_t last = a.n - 1u;  // n > 0: the grid has a block per tile
   uint32_t cf_r[CULL_ROUNDS];
   bool tv_r[CULL_ROUNDS];
   uint32_t bits0_r[CULL_ROUNDS];
+  uint32_t tv_raw[CULL_ROUNDS];
+#pragma unroll
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t i = min(tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t, last);
+    cf_r[round] = a.cflags[i];
+    tv_raw[round] = a.tvis[i];
+    bits0_r[round] = a.masks[i];
+  }
+  // this tile's scanned offset of row t (rows beyond 256 are fetched later)
+  const uint32_t my_row = min(t, rows - 1u);
+  const uint32_t my_offset = a.tile_offsets[(uint64_t)my_row * a.tiles_stride + tile];
+  uint32_t before[3];  // clamped totals of the buckets before row t's bucket in its view
+#pragma unroll
+  for (uint32_t b = 0; b < 3u; ++b) before[b] = min(a.row_totals[min((my_row & ~3u) + b, rows - 1u)], cap);
 #pragma unroll
   for (int round = 0; round < CULL_ROUNDS; ++round) {
     const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
-    const bool valid = i < a.n;
-    cf_r[round] = valid ? a.cflags[i] : 0xf0u;
-    tv_r[round] = valid ? a.tvis[i] != 0 : false;
-    bits0_r[round] = valid ? a.masks[i] : 0u;
+    const uint32_t vm = i < a.n ? 0xffffffffu : 0u;
+    cf_r[round] = (cf_r[round] & vm) | (0xf0u & ~vm);
+    tv_r[round] = (tv_raw[round] & vm) != 0u;
+    bits0_r[round] &= vm;
   }
 
   // phase 1: per-(round, wave) survivor counts of every row
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
   // exclusive prefix over the 16 (round, wave) slots in candidate order, on top
   // of the tile's scanned offset
   for (uint32_t r = t; r < rows; r += CULL_BLOCK) {
-    uint32_t run = a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
+    uint32_t run = r == t ? my_offset : a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
     a.tile_offsets[(uint64_t)r * a.tiles_stride + tile] = 0u;  // ready for the next frame's counts
 #pragma unroll
     for (int slot = 0; slot < CULL_ROUNDS * 4; ++slot) {
@@ -583,10 +600,16 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
       s_cnt[slot][r] = run;
       run += c;
     }
-    // start of the row's bucket inside its view: the clamped totals of the buckets before it
+    // start of the row's bucket inside its view
     uint32_t range = 0u;
-    if (r < a.views * 4u)
-      for (uint32_t b = 0; b < (r & 3u); ++b) range += min(a.row_totals[(r & ~3u) + b], cap);
+    if (r < a.views * 4u) {
+      if (r == t) {
+#pragma unroll
+        for (uint32_t b = 0; b < 3u; ++b) range += b < (r & 3u) ? before[b] : 0u;
+      } else {
+        for (uint32_t b = 0; b < (r & 3u); ++b) range += min(a.row_totals[(r & ~3u) + b], cap);
+      }
+    }
     s_range[r] = range;
   }
   if (blockIdx.x == 0)

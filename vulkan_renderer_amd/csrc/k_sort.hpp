@@ -352,39 +352,52 @@ __host__ __device__ __forceinline__ uint32_t encode_scene_object_id(uint32_t ren
   return render_id + 1u;
 }
 
-// One 16-byte piece of output row `row` (descending order) for sort key `key`:
-// vkr_transparent_draw_emit, lib/src/renderer/vkr_visibility.c:15-35. Pieces 0-2
-// are the VkrDrawItem, 3-7 the VkrInstanceDataGPU; eight lanes take one row so
-// that each output array is written in consecutive 16-byte pieces.
-__device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32_t row,
-                                                       uint64_t key, uint32_t piece) {
+// Output rows of vkr_transparent_draw_emit (lib/src/renderer/vkr_visibility.c:15-35)
+// are written as 16-byte pieces: pieces 0-2 are the VkrDrawItem, 3-7 the
+// VkrInstanceDataGPU; eight lanes take one row so that each output array is
+// written in consecutive 16-byte pieces. Split in two so that a caller can
+// request the gathered inputs before it knows the output row.
+//
+// The part of piece `piece` that does not depend on the output row.
+__device__ __forceinline__ uint4 emit_piece_gather(const EmitArgs &a, uint64_t key,
+                                                   uint32_t piece) {
   // the low word is source_index + 1 (application.h:657-658)
   const uint32_t i = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
+  if (piece == 0u) return a.ident[(uint64_t)i * 2u];  // mesh.id/.generation, geometry.id/.generation
+  if (piece == 1u) {
+    const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
+    return make_uint4(id1.x, id1.y, id1.z, 1u);  // submesh_index, material, instance_count
+  }
+  if (piece == 2u) return make_uint4(0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
+  if (piece < 7u) {
+    const uint64_t nd = a.node ? a.node[i] : i;
+    const float4 c = a.world[nd * 4u + (piece - 3u)];
+    return make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z),
+                      __float_as_uint(c.w));
+  }
+  const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
+  return make_uint4(encode_scene_object_id(id1.w), 0u, 0u, 0u);
+}
+
+__device__ __forceinline__ void emit_piece_store(const EmitArgs &a, uint32_t row, uint64_t key,
+                                                 uint32_t piece, uint4 o) {
   if (piece < 3u) {
-    uint4 o;
-    if (piece == 0u) {
-      o = a.ident[(uint64_t)i * 2u];  // mesh.id, mesh.generation, geometry.id, geometry.generation
-    } else if (piece == 1u) {
-      const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
-      o = make_uint4(id1.x, id1.y, id1.z, 1u);  // submesh_index, material, instance_count
-    } else {
-      o = make_uint4(row, 0u, (uint32_t)key, (uint32_t)(key >> 32));  // first_instance, pad, key
+    if (piece == 2u) {
+      o.x = row;  // first_instance
       a.out_keys[row] = key;
-      a.out_source[row] = i;
+      a.out_source[row] = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
     }
     a.draws[(uint64_t)row * 3u + piece] = o;
   } else {
-    const uint32_t c = piece - 3u;
-    float4 o;
-    if (c < 4u) {
-      const uint64_t nd = a.node ? a.node[i] : i;
-      o = a.world[nd * 4u + c];
-    } else {
-      const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
-      o = make_float4(__uint_as_float(encode_scene_object_id(id1.w)), 0.f, 0.f, 0.f);
-    }
-    a.instances[(uint64_t)row * 5u + c] = o;
+    a.instances[(uint64_t)row * 5u + (piece - 3u)] =
+        make_float4(__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z),
+                    __uint_as_float(o.w));
   }
+}
+
+__device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32_t row,
+                                                       uint64_t key, uint32_t piece) {
+  emit_piece_store(a, row, key, piece, emit_piece_gather(a, key, piece));
 }
 
 // Emission from the ascending-sorted key array, read backwards.
@@ -458,6 +471,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_
       mine[k] = all[min(i, count - 1u)];
       greater[k] = 0u;
     }
+    // lane = 8 * key slot + piece: its piece of its row is gathered while the
+    // sweep below works out where the row goes
+    const uint32_t own = min(g * RANK_WAVE_KEYS + (lane >> 3), count - 1u);
+    const uint64_t own_key = all[own];
+    const uint4 own_piece = emit_piece_gather(a, own_key, lane & 7u);
     for (uint32_t base = 0; base < count; base += 256u) {
       uint64_t other[4];
 #pragma unroll
@@ -468,14 +486,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_
         for (int k = 0; k < RANK_WAVE_KEYS; ++k)
           greater[k] += (uint32_t)__popcll(__ballot(other[u] > mine[k]));
     }
-    // lane = 8 * key slot + piece
     const uint32_t slot = lane >> 3;
     uint32_t row = 0u;
 #pragma unroll
     for (int k = 0; k < RANK_WAVE_KEYS; ++k)
       if (slot == (uint32_t)k) row = greater[k];
-    const uint32_t i = g * RANK_WAVE_KEYS + slot;
-    if (i < count) emit_transparent_piece(a, row, all[i], lane & 7u);
+    if (g * RANK_WAVE_KEYS + slot < count) emit_piece_store(a, row, own_key, lane & 7u, own_piece);
   }
 }
 
