@@ -547,12 +547,17 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
     tv_raw[round] = a.tvis[i];
     bits0_r[round] = a.masks[i];
   }
-  // this tile's scanned offset of row t (rows beyond 256 are fetched later)
-  const uint32_t my_row = min(t, rows - 1u);
-  const uint32_t my_offset = a.tile_offsets[(uint64_t)my_row * a.tiles_stride + tile];
-  uint32_t before[3];  // clamped totals of the buckets before row t's bucket in its view
+  // Sixteen lanes per row turn the row's (round, wave) counts into start
+  // indices; the tile's scanned offset and the totals of the buckets before the
+  // row's bucket are requested now for the first 16 rows (more rows: later).
+  constexpr uint32_t SLOTS = CULL_ROUNDS * 4;
+  const uint32_t slot = t % SLOTS;
+  const uint32_t first_row = min(t / SLOTS, rows - 1u);
+  const uint32_t first_offset = a.tile_offsets[(uint64_t)first_row * a.tiles_stride + tile];
+  uint32_t first_before[3];
 #pragma unroll
-  for (uint32_t b = 0; b < 3u; ++b) before[b] = min(a.row_totals[min((my_row & ~3u) + b, rows - 1u)], cap);
+  for (uint32_t b = 0; b < 3u; ++b)
+    first_before[b] = min(a.row_totals[min((first_row & ~3u) + b, rows - 1u)], cap);
 #pragma unroll
   for (int round = 0; round < CULL_ROUNDS; ++round) {
     const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
@@ -590,27 +595,38 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
   }
   __syncthreads();
   // exclusive prefix over the 16 (round, wave) slots in candidate order, on top
-  // of the tile's scanned offset
-  for (uint32_t r = t; r < rows; r += CULL_BLOCK) {
-    uint32_t run = r == t ? my_offset : a.tile_offsets[(uint64_t)r * a.tiles_stride + tile];
-    a.tile_offsets[(uint64_t)r * a.tiles_stride + tile] = 0u;  // ready for the next frame's counts
+  // of the tile's scanned offset: a 16-lane shuffle scan per row
+  for (uint32_t r0 = 0; r0 < rows; r0 += CULL_BLOCK / SLOTS) {
+    const uint32_t r = r0 + t / SLOTS;
+    const bool live = r < rows;
+    const uint32_t rc = live ? r : rows - 1u;
+    const uint32_t c = live ? s_cnt[slot][rc] : 0u;
+    uint32_t incl = c;
 #pragma unroll
-    for (int slot = 0; slot < CULL_ROUNDS * 4; ++slot) {
-      const uint32_t c = s_cnt[slot][r];
-      s_cnt[slot][r] = run;
-      run += c;
+    for (uint32_t d = 1; d < SLOTS; d <<= 1) {
+      const uint32_t u = __shfl_up(incl, d, SLOTS);
+      if (slot >= d) incl += u;
     }
-    // start of the row's bucket inside its view
-    uint32_t range = 0u;
-    if (r < a.views * 4u) {
-      if (r == t) {
+    uint32_t offset = first_offset;
+    uint32_t before[3] = {first_before[0], first_before[1], first_before[2]};
+    if (r0 != 0u) {
+      offset = a.tile_offsets[(uint64_t)rc * a.tiles_stride + tile];
 #pragma unroll
-        for (uint32_t b = 0; b < 3u; ++b) range += b < (r & 3u) ? before[b] : 0u;
-      } else {
-        for (uint32_t b = 0; b < (r & 3u); ++b) range += min(a.row_totals[(r & ~3u) + b], cap);
+      for (uint32_t b = 0; b < 3u; ++b) before[b] = min(a.row_totals[min((rc & ~3u) + b, rows - 1u)], cap);
+    }
+    if (live) {
+      s_cnt[slot][r] = offset + incl - c;
+      if (slot == 0u) {
+        a.tile_offsets[(uint64_t)r * a.tiles_stride + tile] = 0u;  // ready for the next frame
+        // start of the row's bucket inside its view
+        uint32_t range = 0u;
+        if (r < a.views * 4u) {
+#pragma unroll
+          for (uint32_t b = 0; b < 3u; ++b) range += b < (r & 3u) ? before[b] : 0u;
+        }
+        s_range[r] = range;
       }
     }
-    s_range[r] = range;
   }
   if (blockIdx.x == 0)
     for (uint32_t v = t; v < a.views; v += CULL_BLOCK)
