@@ -11,26 +11,30 @@
 // Three launches:
 //   classify    one thread per candidate; the world matrix (64 B), local sphere
 //               (16 B) and flags (4 B) are read once for ALL views (planes are
-//               wave-uniform scalar loads). Writes one visibility bit per view,
-//               the blend-row visibility byte and sort key, and adds per-tile
-//               survivor counts per (view, bucket) row. It exists stand-alone
-//               (k_classify) and fused behind the transform of the same node
-//               (k_fused.hpp).
-//   k_scan      exclusive scan of the tile counts of every row (one block per
-//               row) and the row totals.
-//   k_scatter   4-bucket prefix of vk_gpu_draw_prefix per view from the row
-//               totals; re-reads the bit masks (not the matrices) and writes candidate
-//               indices at tile base + wave-ballot rank. Order inside a bucket
-//               is ascending candidate index, one of the orders the
-//               reference's atomics can produce.
+//               wave-uniform scalar loads). A block works on one SEGMENT of at
+//               most 1024 consecutive candidates. It keeps the per-view verdict
+//               bits in LDS, and when the segment is done it packs the
+//               survivors of every (view, bucket) row - ascending candidate
+//               index, buckets back to back - into the segment's own stretch
+//               of a staging list and stores the row counts. Only survivors
+//               are written, nothing per candidate except the blend-row
+//               visibility byte. It exists stand-alone (k_classify) and fused
+//               behind the transform of the same node (k_fused.hpp).
+//   k_scan      exclusive scan of the segment counts of every row (one block
+//               per row) and the row totals.
+//   k_gather    4-bucket prefix of vk_gpu_draw_prefix per view from the row
+//               totals; one wave per segment moves the segment's staged runs to
+//               their final offsets (traffic proportional to the survivors).
+//               Order inside a bucket is ascending candidate index, one of the
+//               orders the reference's atomics can produce.
 #pragma once
 #include "device_math.hpp"
 
 namespace vkr {
-
 constexpr int CULL_BLOCK = 256;
 constexpr int CULL_ROUNDS = 4;
-constexpr int CULL_TILE = CULL_BLOCK * CULL_ROUNDS;  // candidates per count tile
+constexpr int CULL_TILE = CULL_BLOCK * CULL_ROUNDS;  // candidates per segment (at most)
+constexpr int CULL_SLOTS = CULL_ROUNDS * (CULL_BLOCK / 64);  // (round, wave) pairs of a segment
 constexpr int CULL_MAX_VIEWS = 64;
 constexpr int CULL_MAX_ROWS = CULL_MAX_VIEWS * 4 + 1;  // (view,bucket) rows + transparent row
 constexpr int MAT_LDS_STRIDE = 5;  // float4 per staged matrix (80 B: conflict-free b128 reads)
@@ -117,43 +121,71 @@ struct CullArgs {
   const float *tie_eps;    // views x 6: eps * max(1,|d|)
   const uint32_t *required;
   const float4 *view;      // camera view matrix columns
-  uint32_t *masks;         // [word][mask_stride]
   uint8_t *tvis;           // transparent_visible
   uint64_t *tkey;          // sort key of visible blend rows (sparse, per candidate)
   float4 *world_bounds;    // optional (cx,cy,cz,r) per candidate
-  uint32_t *tile_counts;   // [row][tiles_stride], zeroed before the frame
+  uint32_t *stage;         // [views + 1][stage_stride] segment-local survivor lists (candidate
+                           // indices); list `views` holds the visible blend rows
+  uint32_t *seg_counts;    // [row][seg_stride] survivors of the row in the segment
+  uint32_t *seg_first;     // [seg_stride] first candidate of the segment
   uint32_t *counters;        // [STAT_SHARDS][CNT_COUNT]
   unsigned long long *ties;  // [TIE_SHARDS][CULL_MAX_VIEWS]
   uint64_t n;
-  uint64_t mask_stride;
-  uint64_t tiles_stride;
+  uint64_t stage_stride;
+  uint64_t seg_stride;
   uint64_t index_base;
   uint32_t views;
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// LDS accumulators of one classify block.
+// LDS working set of one classify block, carved out of dynamic shared memory
+// (its size depends on the view count):
+//   cnt   [CULL_SLOTS][rows]  survivors per (round, wave) slot and row; turned into
+//                             start positions inside the segment when it is done
+//   bits  [CULL_ROUNDS][words][CULL_BLOCK]  per-view verdict bits of every candidate
+//   ties  [views], stat [4]
 struct CullShared {
-  uint32_t cnt[CULL_MAX_ROWS];
-  uint32_t stat[4];
-  uint32_t ties[CULL_MAX_VIEWS];
+  uint32_t *cnt;
+  uint32_t *bits;
+  uint32_t *ties;
+  uint32_t *stat;
+  uint32_t rows;
+  uint32_t words;
 };
 
-__device__ __forceinline__ void cull_shared_clear(CullShared &s, uint32_t views) {
+__host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
+  const uint32_t rows = views * 4u + 1u, words = (views + 31u) / 32u;
+  return sizeof(uint32_t) * ((size_t)CULL_SLOTS * rows + (size_t)CULL_ROUNDS * words * CULL_BLOCK +
+                             views + 4u);
+}
+
+__device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
+  extern __shared__ uint32_t cull_lds[];
+  CullShared s;
+  s.rows = views * 4u + 1u;
+  s.words = (views + 31u) >> 5;
+  s.cnt = cull_lds;
+  s.bits = s.cnt + CULL_SLOTS * s.rows;
+  s.ties = s.bits + CULL_ROUNDS * s.words * CULL_BLOCK;
+  s.stat = s.ties + views;
   const uint32_t t = threadIdx.x;
-  for (uint32_t r = t; r < views * 4u + 1u; r += blockDim.x) s.cnt[r] = 0u;
-  if (t < 4) s.stat[t] = 0u;
-  for (uint32_t r = t; r < views; r += blockDim.x) s.ties[r] = 0u;
+  // cnt, bits (rounds a block does not run must read as "nobody survives"), ties, stat
+  const uint32_t total = CULL_SLOTS * s.rows + CULL_ROUNDS * s.words * CULL_BLOCK + views + 4u;
+  for (uint32_t k = t; k < total; k += blockDim.x) cull_lds[k] = 0u;
+  return s;
 }
 
 // Classifies one candidate against every view. Must be called by all threads of
-// the wave (it votes). `valid` lanes own candidate i with model matrix m.
+// the wave (it votes). `valid` lanes own candidate i with model matrix m;
+// `round` is the candidate's 256-wide round inside its segment. Returns the
+// lane's state bucket (bits 0-3) and blend-row visibility (bit 4).
 template <bool TIES, bool BOUNDS_OUT>
-__device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared &s, uint64_t i,
-                                                   bool valid, const Mat4 &m, float4 ls,
-                                                   uint32_t cf) {
+__device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullShared &s,
+                                                       uint32_t round, uint64_t i, bool valid,
+                                                       const Mat4 &m, float4 ls, uint32_t cf) {
   const bool leader = lane_id() == 0;
+  uint32_t *cnt = s.cnt + (round * (CULL_BLOCK / 64u) + (threadIdx.x >> 6)) * s.rows;
   // world sphere: vkr_visibility.c:40-49 / deferred.slang:325-333
   const float3 c = mat4_mul_point(m, ls.x, ls.y, ls.z);
   const float radius = ls.w * max_basis_length(m);
@@ -193,7 +225,7 @@ __device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared
     const unsigned long long mo = __ballot(valid && (cf & CF_CAMERA_OPAQUE));
     const unsigned long long mx = __ballot(valid && (cf & CF_TRANSMISSIVE));
     if (leader) {
-      if (mt) atomicAdd(&s.cnt[a.views * 4u], (uint32_t)__popcll(mt));
+      cnt[a.views * 4u] = (uint32_t)__popcll(mt);
       if (mb) atomicAdd(&s.stat[0], (uint32_t)__popcll(mb));
       if (mc) atomicAdd(&s.stat[1], (uint32_t)__popcll(mc));
       if (mo) atomicAdd(&s.stat[2], (uint32_t)__popcll(mo));
@@ -202,11 +234,10 @@ __device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared
   }
 
   // views: deferred.slang:316-351
-  const uint32_t words = (a.views + 31u) >> 5;
   unsigned long long in_bucket[4];  // lanes of the wave per state bucket (wave-uniform)
 #pragma unroll
   for (uint32_t q = 0; q < 4u; ++q) in_bucket[q] = __ballot(bucket == q);
-  for (uint32_t w = 0; w < words; ++w) {
+  for (uint32_t w = 0; w < s.words; ++w) {
     uint32_t bits = 0u;
     const uint32_t vend = min(a.views, (w + 1u) * 32u);
     for (uint32_t v = w * 32u; v < vend; ++v) {
@@ -231,30 +262,88 @@ __device__ __forceinline__ void classify_candidate(const CullArgs &a, CullShared
       }
       if (pass) bits |= 1u << (v & 31u);
       const unsigned long long mp = __ballot(pass);
-      if (leader && mp) {
+      if (leader) {
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-          const uint32_t nq = (uint32_t)__popcll(mp & in_bucket[q]);
-          if (nq) atomicAdd(&s.cnt[v * 4u + q], nq);
+        for (uint32_t q = 0; q < 4u; ++q) cnt[v * 4u + q] = (uint32_t)__popcll(mp & in_bucket[q]);
+      }
+    }
+    s.bits[(round * s.words + w) * CULL_BLOCK + threadIdx.x] = bits;
+  }
+  return (bucket & 0xfu) | (tv ? 0x10u : 0u);
+}
+
+// Ends a segment: turns the slot counts into start positions, stores the row
+// counts, packs the survivors into the segment's stretch of the staging lists
+// and flushes the statistics. `packed` holds classify_candidate's return value
+// of the thread's candidate in round r in bits [8r, 8r+5); candidate (round r,
+// thread t) is segment-relative index `rel0 + 256 r + t`, the segment's staging
+// stretch starts at candidate `first`, and rel0 = (tile start) - first may be
+// "negative" (wraps): only survivors' indices are formed.
+template <bool TIES>
+__device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s, uint64_t seg,
+                                               uint64_t first, uint32_t tile_to_first,
+                                               uint32_t packed) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = t >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  __syncthreads();
+  // Sixteen lanes per row: exclusive prefix over the (round, wave) slots in
+  // candidate order. A wave holds the four bucket rows of one view, so the
+  // starts of buckets 1-3 behind bucket 0 come from three shuffles.
+  for (uint32_t r0 = 0; r0 < s.rows; r0 += CULL_BLOCK / CULL_SLOTS) {
+    const uint32_t slot = t % CULL_SLOTS;
+    const uint32_t r = r0 + t / CULL_SLOTS;
+    const bool live = r < s.rows;
+    const uint32_t c = live ? s.cnt[slot * s.rows + r] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (uint32_t d = 1; d < CULL_SLOTS; d <<= 1) {
+      const uint32_t u = __shfl_up(incl, d, CULL_SLOTS);
+      if (slot >= d) incl += u;
+    }
+    const uint32_t t0 = __shfl(incl, 15, 64), t1 = __shfl(incl, 31, 64), t2 = __shfl(incl, 47, 64);
+    const uint32_t b = lane >> 4;  // bucket of the row inside its view
+    const uint32_t bucket_start = (b > 0u ? t0 : 0u) + (b > 1u ? t1 : 0u) + (b > 2u ? t2 : 0u);
+    if (live) {
+      s.cnt[slot * s.rows + r] = bucket_start + incl - c;
+      if (slot == CULL_SLOTS - 1u) a.seg_counts[(uint64_t)r * a.seg_stride + seg] = incl;
+    }
+  }
+  if (t == 0) a.seg_first[seg] = (uint32_t)first;
+  __syncthreads();
+
+#pragma unroll
+  for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
+    const uint32_t bucket = (packed >> (8u * round)) & 0xfu;
+    const bool tv = ((packed >> (8u * round)) & 0x10u) != 0u;
+    const uint32_t rel = round * CULL_BLOCK + t - tile_to_first;  // candidate index - first
+    const uint32_t *start = s.cnt + (round * (CULL_BLOCK / 64u) + wave) * s.rows;
+    unsigned long long below_same_bucket = 0ull;  // lower lanes holding this lane's bucket
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+      const unsigned long long mb = __ballot(bucket == q);
+      if (bucket == q) below_same_bucket = mb & lt_mask;
+    }
+    for (uint32_t w = 0; w < s.words; ++w) {
+      const uint32_t bits = s.bits[(round * s.words + w) * CULL_BLOCK + t];
+      if (__ballot(bits != 0u) == 0ull) continue;  // nobody of the wave survives these views
+      const uint32_t vend = min(a.views, (w + 1u) * 32u);
+      for (uint32_t v = w * 32u; v < vend; ++v) {
+        const bool pass = (bits >> (v & 31u)) & 1u;
+        const unsigned long long mp = __ballot(pass);
+        if (pass) {
+          const uint32_t pos = start[v * 4u + bucket] + (uint32_t)__popcll(mp & below_same_bucket);
+          a.stage[(uint64_t)v * a.stage_stride + first + pos] = (uint32_t)first + rel;
         }
       }
     }
-    if (valid) a.masks[(uint64_t)w * a.mask_stride + i] = bits;
+    const unsigned long long mt = __ballot(tv);
+    if (tv) {
+      const uint32_t pos = start[a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
+      a.stage[(uint64_t)a.views * a.stage_stride + first + pos] = (uint32_t)first + rel;
+    }
   }
-}
-
-// Adds the block's accumulators to the global tile counts / counters. All
-// candidates of the block must lie in count tile `tile`.
-template <bool TIES>
-__device__ __forceinline__ void cull_shared_flush(const CullArgs &a, CullShared &s,
-                                                  uint64_t tile) {
-  const uint32_t t = threadIdx.x;
-  const uint32_t rows = a.views * 4u + 1u;
-  __syncthreads();
-#ifndef VKR_EXP_NO_TILE_ATOMICS
-  for (uint32_t r = t; r < rows; r += blockDim.x)
-    if (s.cnt[r]) atomicAdd(&a.tile_counts[(uint64_t)r * a.tiles_stride + tile], s.cnt[r]);
-#endif
   if (t == 0) {
     uint32_t *shard = a.counters + stat_shard();
     if (s.stat[0]) atomicAdd(&shard[CNT_WITHOUT_BOUNDS], s.stat[0]);
@@ -269,60 +358,74 @@ __device__ __forceinline__ void cull_shared_flush(const CullArgs &a, CullShared 
                   (unsigned long long)s.ties[r]);
 }
 
-// Stand-alone classify: one block per 256 candidates. With the identity
-// candidate->node mapping the matrices arrive as coalesced 16-byte loads staged
-// through LDS (thread t then reads its own four columns); otherwise each thread
-// gathers its node's matrix.
+// A segment without candidates still owns a column of the count table.
+__device__ __forceinline__ void segment_empty(const CullArgs &a, uint64_t seg) {
+  for (uint32_t r = threadIdx.x; r < a.views * 4u + 1u; r += blockDim.x)
+    a.seg_counts[(uint64_t)r * a.seg_stride + seg] = 0u;
+}
+
+// Stand-alone classify: one block per segment of 1024 candidates, four rounds of
+// 256. With the identity candidate->node mapping the matrices arrive as
+// coalesced 16-byte loads staged through LDS (thread t then reads its own four
+// columns); otherwise each thread gathers its node's matrix.
 template <bool IDENTITY, bool TIES, bool BOUNDS_OUT>
 __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
   __shared__ float4 s_mat[IDENTITY ? CULL_BLOCK * MAT_LDS_STRIDE : 1];
-  __shared__ CullShared s;
+  CullShared s = cull_shared_init(a.views);
   const uint32_t t = threadIdx.x;
-  cull_shared_clear(s, a.views);
+  const uint64_t seg = blockIdx.x;
+  const uint64_t first = seg * CULL_TILE;
+  const uint64_t last = a.n - 1u;  // n > 0: the grid has a block per segment
+  uint32_t packed = 0u;
+  __syncthreads();  // accumulators cleared
 
-  const uint64_t base = (uint64_t)blockIdx.x * CULL_BLOCK;
-  const uint64_t i = base + t;
-  const bool valid = i < a.n;
-  float4 ls = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t cf = 0xf0u;  // invalid bucket: fails every gate
-  if (valid) {
-    ls = a.sphere[i];
-    cf = a.cflags[i];
+  // all rounds' small inputs are requested up front (clamped, unconditional)
+  float4 ls_r[CULL_ROUNDS];
+  uint32_t cf_r[CULL_ROUNDS];
+#pragma unroll
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t i = min(first + (uint64_t)round * CULL_BLOCK + t, last);
+    ls_r[round] = a.sphere[i];
+    cf_r[round] = a.cflags[i];
   }
-  Mat4 m;
-  if (IDENTITY) {
-    const uint64_t total4 = a.n * 4u;
-    float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint64_t g = base * 4u + t + 256u * (uint32_t)k;
-      v[k] = g < total4 ? a.world[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  for (int round = 0; round < CULL_ROUNDS; ++round) {
+    const uint64_t base = first + (uint64_t)round * CULL_BLOCK;
+    if (base >= a.n) break;  // block-uniform
+    const uint64_t i = base + t;
+    const bool valid = i < a.n;
+    const uint32_t vm = valid ? 0xffffffffu : 0u;
+    const uint32_t cf = (cf_r[round] & vm) | (0xf0u & ~vm);  // invalid bucket: fails every gate
+    Mat4 m;
+    if (IDENTITY) {
+      const uint64_t last4 = a.n * 4u - 1u;
+      float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t l = t + 256u * (uint32_t)k;
-      s_mat[(l >> 2) * MAT_LDS_STRIDE + (l & 3u)] = v[k];
-    }
-    __syncthreads();
-    const float4 *p = s_mat + t * MAT_LDS_STRIDE;
-    m.c[0] = p[0];
-    m.c[1] = p[1];
-    m.c[2] = p[2];
-    m.c[3] = p[3];
-  } else {
-    __syncthreads();  // s cleared
-    if (valid) {
-      const float4 *p = a.world + (uint64_t)a.node[i] * 4u;
+      for (int k = 0; k < 4; ++k) v[k] = a.world[min(base * 4u + t + 256u * (uint32_t)k, last4)];
+      __syncthreads();  // the previous round's readers of s_mat are done
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t l = t + 256u * (uint32_t)k;
+        s_mat[(l >> 2) * MAT_LDS_STRIDE + (l & 3u)] = v[k];
+      }
+      __syncthreads();
+      const float4 *p = s_mat + t * MAT_LDS_STRIDE;
       m.c[0] = p[0];
       m.c[1] = p[1];
       m.c[2] = p[2];
       m.c[3] = p[3];
     } else {
-      m.c[0] = m.c[1] = m.c[2] = m.c[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 *p = a.world + (uint64_t)a.node[min(i, last)] * 4u;
+      m.c[0] = p[0];
+      m.c[1] = p[1];
+      m.c[2] = p[2];
+      m.c[3] = p[3];
     }
+    packed |= classify_candidate<TIES, BOUNDS_OUT>(a, s, (uint32_t)round, i, valid, m, ls_r[round],
+                                                   cf)
+              << (8 * round);
   }
-  classify_candidate<TIES, BOUNDS_OUT>(a, s, i, valid, m, ls, cf);
-  cull_shared_flush<TIES>(a, s, base / CULL_TILE);
+  segment_finish<TIES>(a, s, seg, first, 0u, packed);
 }
 
 // ---------------------------------------------------------------------------
@@ -399,11 +502,12 @@ __device__ __forceinline__ uint4 block_exclusive_scan4(uint4 v, uint4 *s_wave4, 
 }
 
 struct ScanArgs {
-  uint32_t *tile_counts;  // [row][tiles_stride], scanned in place
-  uint32_t *row_totals;   // [rows]: survivors per (view, bucket) row and of the transparent row
+  const uint32_t *seg_counts;  // [row][seg_stride]
+  uint32_t *seg_offsets;       // [row][seg_stride] exclusive prefix of the counts
+  uint32_t *row_totals;        // [rows]: survivors per (view, bucket) row and of the transparent row
   uint32_t *counters;
-  uint64_t tiles;  // tiles in use this frame
-  uint64_t tiles_stride;
+  uint64_t segments;  // segments in use this frame
+  uint64_t seg_stride;
   uint32_t views;
   uint64_t transparent_capacity;
   uint32_t *host_hint;   // pinned host word: last frame's transparent count (may be null)
@@ -413,17 +517,28 @@ struct ScanArgs {
 
 __device__ __forceinline__ uint32_t sum4(uint4 v) { return v.x + v.y + v.z + v.w; }
 
-// Exclusive scan of the tile counts, one 1024-thread block per row. A wave owns a
-// contiguous run of the row and reads it 64 x 16 bytes at a time (coalesced);
-// sweep 1 only totals each wave's run, one barrier combines the 16 totals, and
-// sweep 2 re-reads the run (from cache), scans it 64 uint4 at a time with wave
-// shuffles and writes the exclusive prefix in place: two memory round trips for
-// any tile count. Rows are padded with zeros to whole uint4s.
+// One uint4 of a count row; entries at or beyond `segments` read as zero (the
+// rows are padded to whole uint4s and the padding is never written).
+__device__ __forceinline__ uint4 load_counts4(const uint4 *row, uint64_t q, uint64_t segments) {
+  uint4 v = row[q];
+  if (q * 4u + 1u >= segments) v.y = 0u;
+  if (q * 4u + 2u >= segments) v.z = 0u;
+  if (q * 4u + 3u >= segments) v.w = 0u;
+  return v;
+}
+
+// Exclusive scan of the segment counts, one 1024-thread block per row. A wave
+// owns a contiguous run of the row and reads it 64 x 16 bytes at a time
+// (coalesced); sweep 1 only totals each wave's run, one barrier combines the 16
+// totals, and sweep 2 re-reads the run (from cache), scans it 64 uint4 at a time
+// with wave shuffles and writes the exclusive prefix: two memory round trips for
+// any segment count.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
   __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
   const uint32_t r = blockIdx.x;
-  uint4 *row = reinterpret_cast<uint4 *>(a.tile_counts + (uint64_t)r * a.tiles_stride);
-  const uint64_t quads = (a.tiles + 3u) / 4u;
+  const uint4 *row = reinterpret_cast<const uint4 *>(a.seg_counts + (uint64_t)r * a.seg_stride);
+  uint4 *out = reinterpret_cast<uint4 *>(a.seg_offsets + (uint64_t)r * a.seg_stride);
+  const uint64_t quads = (a.segments + 3u) / 4u;
   const uint32_t w = threadIdx.x >> 6;
   const uint32_t lane = lane_id();
   const uint64_t wave_quads = ((quads + SCAN_BLOCK / 64 - 1) / (SCAN_BLOCK / 64) + 63u) & ~(uint64_t)63u;
@@ -431,7 +546,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
   const uint64_t qe = min(qb + wave_quads, quads);
 
   uint32_t mine = 0u;
-  for (uint64_t q = qb + lane; q < qe; q += 64u) mine += sum4(row[q]);
+  for (uint64_t q = qb + lane; q < qe; q += 64u) mine += sum4(load_counts4(row, q, a.segments));
   const uint32_t wave_total = (uint32_t)__shfl((int)wave_inclusive_scan(mine), 63, 64);
   if (lane == 0) s_wave[w] = wave_total;
   __syncthreads();
@@ -444,7 +559,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
   for (uint64_t q0 = qb; q0 < qe; q0 += 64u) {  // wave-uniform trip count
     const uint64_t q = q0 + lane;
     const bool valid = q < qe;
-    const uint4 v = valid ? row[q] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 v = valid ? load_counts4(row, q, a.segments) : make_uint4(0u, 0u, 0u, 0u);
     const uint32_t s = sum4(v);
     const uint32_t incl = wave_inclusive_scan(s);
     uint4 o;
@@ -452,11 +567,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
     o.y = o.x + v.x;
     o.z = o.y + v.y;
     o.w = o.z + v.z;
-    // the padding of the last uint4 stays zero: it may be a real tile next frame
-    if (q * 4u + 1u >= a.tiles) o.y = 0u;
-    if (q * 4u + 2u >= a.tiles) o.z = 0u;
-    if (q * 4u + 3u >= a.tiles) o.w = 0u;
-    if (valid) row[q] = o;
+    if (valid) out[q] = o;
     carry += (uint32_t)__shfl((int)incl, 63, 64);
   }
   if (r == 0 && a.clear != nullptr)
@@ -498,19 +609,18 @@ __device__ __forceinline__ CompactionState prefix_state(const uint32_t *totals4,
   return st;
 }
 
-struct ScatterArgs {
-  const uint32_t *masks;
-  const uint32_t *cflags;
-  const uint8_t *tvis;
+struct GatherArgs {
+  const uint32_t *stage;        // [views + 1][stage_stride]
+  const uint32_t *seg_offsets;  // [row][seg_stride], from k_scan
+  const uint32_t *seg_first;
+  const uint32_t *row_totals;
   const uint64_t *tkey;
-  uint32_t *tile_offsets;        // scanned tile counts; zeroed again once consumed
-  const uint32_t *row_totals;    // from k_scan
-  CompactionState *states;       // written by block 0
-  uint32_t *visible;  // [view][visible_stride]
-  uint64_t *keys;     // compacted sort keys of the visible blend rows
-  uint64_t n;
-  uint64_t mask_stride;
-  uint64_t tiles_stride;
+  CompactionState *states;  // written by block 0
+  uint32_t *visible;        // [view][visible_stride]
+  uint64_t *keys;           // compacted sort keys of the visible blend rows
+  uint64_t segments;
+  uint64_t stage_stride;
+  uint64_t seg_stride;
   uint64_t visible_stride;
   uint64_t transparent_capacity;
   uint64_t index_base;
@@ -518,160 +628,98 @@ struct ScatterArgs {
   uint32_t partition_capacity;
 };
 
-__global__ __launch_bounds__(CULL_BLOCK) void k_scatter(ScatterArgs a) {
-  // survivors of (round, wave) per row, turned into bucket-local start indices
-  __shared__ uint32_t s_cnt[CULL_ROUNDS * 4][CULL_MAX_ROWS];
-  __shared__ uint32_t s_range[CULL_MAX_ROWS];  // execution_ranges[b].x of the row's view
+constexpr int GATHER_BLOCK = 256;  // four waves, one segment each
 
+__host__ __device__ inline size_t gather_shared_bytes(uint32_t views) {
+  return sizeof(uint32_t) * 3u * (size_t)(views * 4u + 1u) * (GATHER_BLOCK / 64);
+}
+
+// One wave per segment. The lanes first work out, for every (view, bucket) row,
+// how many staged survivors the segment has (next offset - own offset), where
+// the run sits in the staging list (buckets of a view back to back) and where it
+// goes (bucket start + scanned offset, clamped to the partition capacity); then
+// all runs are copied as one flat list of entries. The visible blend rows take
+// their sort keys along.
+__global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
+  extern __shared__ uint32_t gather_lds[];
   const uint32_t t = threadIdx.x;
-  const uint32_t wave = t >> 6;
   const uint32_t lane = lane_id();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t wave = t >> 6;
   const uint32_t rows = a.views * 4u + 1u;
-  const uint64_t tile = blockIdx.x;
+  const uint32_t vrows = a.views * 4u;
   const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
-  const uint32_t words = (a.views + 31u) >> 5;
+  if (blockIdx.x == 0)
+    for (uint32_t v = t; v < a.views; v += GATHER_BLOCK)
+      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity);
 
-  // All inputs are requested up front with unconditional loads from clamped
-  // indices (a select on a loaded value would become a branch around the load
-  // that waits for it); out-of-range lanes are blanked with integer masks.
-  const uint64_t last = a.n - 1u;  // n > 0: the grid has a block per tile
-  uint32_t cf_r[CULL_ROUNDS];
-  bool tv_r[CULL_ROUNDS];
-  uint32_t bits0_r[CULL_ROUNDS];
-  uint32_t tv_raw[CULL_ROUNDS];
-#pragma unroll
-  for (int round = 0; round < CULL_ROUNDS; ++round) {
-    const uint64_t i = min(tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t, last);
-    cf_r[round] = a.cflags[i];
-    tv_raw[round] = a.tvis[i];
-    bits0_r[round] = a.masks[i];
-  }
-  // Sixteen lanes per row turn the row's (round, wave) counts into start
-  // indices; the tile's scanned offset and the totals of the buckets before the
-  // row's bucket are requested now for the first 16 rows (more rows: later).
-  constexpr uint32_t SLOTS = CULL_ROUNDS * 4;
-  const uint32_t slot = t % SLOTS;
-  const uint32_t first_row = min(t / SLOTS, rows - 1u);
-  const uint32_t first_offset = a.tile_offsets[(uint64_t)first_row * a.tiles_stride + tile];
-  uint32_t first_before[3];
-#pragma unroll
-  for (uint32_t b = 0; b < 3u; ++b)
-    first_before[b] = min(a.row_totals[min((first_row & ~3u) + b, rows - 1u)], cap);
-#pragma unroll
-  for (int round = 0; round < CULL_ROUNDS; ++round) {
-    const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
-    const uint32_t vm = i < a.n ? 0xffffffffu : 0u;
-    cf_r[round] = (cf_r[round] & vm) | (0xf0u & ~vm);
-    tv_r[round] = (tv_raw[round] & vm) != 0u;
-    bits0_r[round] &= vm;
-  }
+  const uint64_t seg = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
+  if (seg >= a.segments) return;  // wave-uniform; no block-wide barrier below
+  uint32_t *e_start = gather_lds + wave * 3u * rows;  // first flat entry of the row
+  uint32_t *e_src = e_start + rows;                   // staging position of the row's run
+  uint32_t *e_dst = e_src + rows;                     // output slot of the row's run
+  const uint32_t first = a.seg_first[seg];
+  const bool last_seg = seg + 1u == a.segments;
 
-  // phase 1: per-(round, wave) survivor counts of every row
-#pragma unroll
-  for (int round = 0; round < CULL_ROUNDS; ++round) {
-    const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
-    const bool valid = i < a.n;
-    const uint32_t bucket = (cf_r[round] >> CF_BUCKET_SHIFT) & 0xfu;
-    uint32_t *cnt = s_cnt[round * 4 + (int)wave];
-    unsigned long long in_bucket[4];  // lanes of the wave per state bucket
-#pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) in_bucket[q] = __ballot(bucket == q);
-    for (uint32_t w = 0; w < words; ++w) {
-      const uint32_t bits =
-          w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
-      const uint32_t vend = min(a.views, (w + 1u) * 32u);
-      for (uint32_t v = w * 32u; v < vend; ++v) {
-        const unsigned long long mp = __ballot((bits >> (v & 31u)) & 1u);
-        if (lane == 0) {
-#pragma unroll
-          for (uint32_t q = 0; q < 4u; ++q)
-            cnt[v * 4u + q] = (uint32_t)__popcll(mp & in_bucket[q]);
-        }
-      }
-    }
-    const unsigned long long mt = __ballot(tv_r[round]);
-    if (lane == 0) cnt[a.views * 4u] = (uint32_t)__popcll(mt);
-  }
-  __syncthreads();
-  // exclusive prefix over the 16 (round, wave) slots in candidate order, on top
-  // of the tile's scanned offset: a 16-lane shuffle scan per row
-  for (uint32_t r0 = 0; r0 < rows; r0 += CULL_BLOCK / SLOTS) {
-    const uint32_t r = r0 + t / SLOTS;
+  uint32_t flat = 0u;       // running number of entries (wave-uniform)
+  uint32_t t_count = 0u, t_offset = 0u;
+  for (uint32_t r0 = 0; r0 < rows; r0 += 64u) {
+    const uint32_t r = r0 + lane;
     const bool live = r < rows;
     const uint32_t rc = live ? r : rows - 1u;
-    const uint32_t c = live ? s_cnt[slot][rc] : 0u;
-    uint32_t incl = c;
+    const uint32_t off = a.seg_offsets[(uint64_t)rc * a.seg_stride + seg];
+    const uint32_t nxt = last_seg ? a.row_totals[rc] : a.seg_offsets[(uint64_t)rc * a.seg_stride + seg + 1u];
+    uint32_t cnt = live ? nxt - off : 0u;
+    // staging: the buckets of a view lie back to back (four lanes per view)
+    uint32_t before = 0u;
 #pragma unroll
-    for (uint32_t d = 1; d < SLOTS; d <<= 1) {
-      const uint32_t u = __shfl_up(incl, d, SLOTS);
-      if (slot >= d) incl += u;
+    for (uint32_t d = 1; d < 4u; ++d) {
+      const uint32_t u = __shfl_up(cnt, d, 4);
+      if ((lane & 3u) >= d) before += u;
     }
-    uint32_t offset = first_offset;
-    uint32_t before[3] = {first_before[0], first_before[1], first_before[2]};
-    if (r0 != 0u) {
-      offset = a.tile_offsets[(uint64_t)rc * a.tiles_stride + tile];
-#pragma unroll
-      for (uint32_t b = 0; b < 3u; ++b) before[b] = min(a.row_totals[min((rc & ~3u) + b, rows - 1u)], cap);
+    // output: start of the bucket inside the view's list, then the scanned offset
+    uint32_t range = 0u;
+    if (live && r < vrows)
+      for (uint32_t b = 0; b < (r & 3u); ++b) range += min(a.row_totals[(r & ~3u) + b], cap);
+    if (r == vrows) {  // the transparent row: copied with its keys below
+      t_count = cnt;
+      t_offset = off;
+      cnt = 0u;
+    } else if (live) {
+      // entries beyond the partition capacity or the list capacity are dropped
+      const uint32_t room = off < cap ? cap - off : 0u;
+      cnt = min(cnt, room);
+      const uint64_t slot0 = (uint64_t)range + off;
+      const uint64_t list_room = slot0 < a.visible_stride ? a.visible_stride - slot0 : 0u;
+      cnt = (uint32_t)min((uint64_t)cnt, list_room);
     }
+    const uint32_t incl = wave_inclusive_scan(cnt);
     if (live) {
-      s_cnt[slot][r] = offset + incl - c;
-      if (slot == 0u) {
-        a.tile_offsets[(uint64_t)r * a.tiles_stride + tile] = 0u;  // ready for the next frame
-        // start of the row's bucket inside its view
-        uint32_t range = 0u;
-        if (r < a.views * 4u) {
-#pragma unroll
-          for (uint32_t b = 0; b < 3u; ++b) range += b < (r & 3u) ? before[b] : 0u;
-        }
-        s_range[r] = range;
-      }
+      e_start[r] = flat + incl - cnt;
+      e_src[r] = first + before;
+      e_dst[r] = range + off;
     }
+    flat += (uint32_t)__shfl((int)incl, 63, 64);
   }
-  if (blockIdx.x == 0)
-    for (uint32_t v = t; v < a.views; v += CULL_BLOCK)
-      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // the row table is read by other lanes of the wave
+  t_count = (uint32_t)__shfl((int)t_count, (int)(vrows & 63u), 64);
+  t_offset = (uint32_t)__shfl((int)t_offset, (int)(vrows & 63u), 64);
 
-  // phase 2: positions
-#pragma unroll
-  for (int round = 0; round < CULL_ROUNDS; ++round) {
-    const uint64_t i = tile * CULL_TILE + (uint64_t)round * CULL_BLOCK + t;
-    const bool valid = i < a.n;
-    const uint32_t bucket = (cf_r[round] >> CF_BUCKET_SHIFT) & 0xfu;
-    const uint32_t *start = s_cnt[round * 4 + (int)wave];
-    unsigned long long below_same_bucket = 0ull;  // lower lanes holding this lane's bucket
-#pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) {
-      const unsigned long long mb = __ballot(bucket == q);
-      if (bucket == q) below_same_bucket = mb & lt_mask;
+  // flat copy: entry e belongs to the last row whose first entry is <= e
+  for (uint32_t e = lane; e < flat; e += 64u) {
+    uint32_t lo = 0u, hi = vrows;  // rows [lo, hi) still possible; e_start is non-decreasing
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (e_start[mid] <= e) lo = mid; else hi = mid;
     }
-    for (uint32_t w = 0; w < words; ++w) {
-      const uint32_t bits =
-          w == 0 ? bits0_r[round] : (valid ? a.masks[(uint64_t)w * a.mask_stride + i] : 0u);
-      const uint32_t vend = min(a.views, (w + 1u) * 32u);
-      for (uint32_t v = w * 32u; v < vend; ++v) {
-        const bool pass = (bits >> (v & 31u)) & 1u;
-        const uint32_t row = v * 4u + (bucket & 3u);
-        // survivors of the same bucket in the lanes below this one
-        const unsigned long long mp = __ballot(pass);
-        const uint32_t rank = (uint32_t)__popcll(mp & below_same_bucket);
-        if (pass) {
-          const uint32_t local = start[row] + rank;
-          if (local < cap) {
-            const uint64_t slot = (uint64_t)s_range[row] + local;
-            if (slot < a.visible_stride)
-              a.visible[(uint64_t)v * a.visible_stride + slot] = (uint32_t)(a.index_base + i);
-          }
-        }
-      }
-    }
-    const bool tv = tv_r[round];
-    const unsigned long long mt = __ballot(tv);
-    if (tv) {
-      const uint64_t pos = (uint64_t)start[a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
-      if (pos < a.transparent_capacity) a.keys[pos] = a.tkey[i];
-    }
+    const uint32_t k = e - e_start[lo];
+    const uint32_t v = lo >> 2;
+    const uint32_t idx = a.stage[(uint64_t)v * a.stage_stride + e_src[lo] + k];
+    a.visible[(uint64_t)v * a.visible_stride + e_dst[lo] + k] = (uint32_t)(a.index_base + idx);
+  }
+  for (uint32_t k = lane; k < t_count; k += 64u) {
+    const uint64_t pos = (uint64_t)t_offset + k;
+    if (pos < a.transparent_capacity)
+      a.keys[pos] = a.tkey[a.stage[(uint64_t)a.views * a.stage_stride + first + k]];
   }
 }
 

@@ -5,8 +5,8 @@
 // just produced is classified before it leaves the CU: it is written to HBM once
 // (world[] is an output) and never re-read by a separate cull launch. Per node
 // the HBM traffic is local 64 B + flags 1 B in, world 64 B + flags 1 B out,
-// sphere 16 B + candidate word 4 B in, view-mask word(s) + visibility byte out
-// (+ parent index 4 B below the root level).
+// sphere 16 B + candidate word 4 B in, visibility byte out (+ parent index 4 B
+// below the root level) and 4 B per surviving (node, view).
 //
 // A block owns one 1024-node count tile (aligned to 1024 in the global node
 // index) and walks it in four rounds of 256 nodes (small levels: half or a
@@ -38,8 +38,9 @@ constexpr int FUSED_WINDOW = 128;                      // LDS-staged parent wind
 
 struct FusedArgs {
   TransformArgs t;
-  CullArgs c;       // c.n = candidates; candidate i <-> node i
-  uint32_t rounds;  // rounds of a tile one block walks: 4, 2 or 1 (more, shorter blocks)
+  CullArgs c;         // c.n = candidates; candidate i <-> node i
+  uint32_t rounds;    // rounds of a tile one block walks: 4, 2 or 1 (more, shorter blocks)
+  uint32_t seg_base;  // cull segment of block 0 of this launch (segments follow launch order)
 };
 
 // min and max of `p` over the lanes of the wave that hold a parent index
@@ -157,7 +158,6 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
   __shared__ float4 s_pworld[HAS_PARENT ? FUSED_WINDOW * 4 : 1];
   __shared__ uint8_t s_pflags[HAS_PARENT ? FUSED_WINDOW : 1];
   __shared__ uint32_t s_par[HAS_PARENT ? FUSED_BLOCK : 1];
-  __shared__ CullShared s;
   __shared__ uint32_t s_wmin[4], s_wmax[4], s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
 
@@ -174,9 +174,14 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
   uint32_t hi = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tile_base);
   lo = max(lo, first_round * FUSED_BLOCK);
   hi = min(hi, (first_round + a.rounds) * FUSED_BLOCK);
-  if (lo >= hi) return;  // block-uniform
+  const uint64_t seg = (uint64_t)a.seg_base + blockIdx.x;  // block order is candidate order
+  if (lo >= hi) {  // block-uniform
+    segment_empty(a.c, seg);
+    return;
+  }
   if (t == 0) s_updated = 0u;
-  cull_shared_clear(s, a.c.views);
+  CullShared s = cull_shared_init(a.c.views);
+  uint32_t packed = 0u;  // per round: state bucket and blend-row visibility of this thread's candidate
 
   // rounds of the tile that overlap the level (block-uniform)
   auto active = [&](int r) {
@@ -297,10 +302,12 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       m.c[3] = p[3];
     }
     const bool cvalid = rbase + t >= lo && rbase + t < hi && base + t < a.c.n;
-    classify_candidate<TIES, BOUNDS_OUT>(a.c, s, base + t, cvalid, m, hd.ls, hd.cf);
+    packed |= classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, m,
+                                                   hd.ls, hd.cf)
+              << (8 * round);
   }
   if ((t & 63u) == 0 && updated_here) atomicAdd(&s_updated, updated_here);
-  cull_shared_flush<TIES>(a.c, s, tile);
+  segment_finish<TIES>(a.c, s, seg, tile_base + lo, lo, packed);
   if (t == 0 && s_updated) atomicAdd(a.t.counters + stat_shard() + CNT_NODES_UPDATED, s_updated);
 }
 

@@ -78,22 +78,25 @@ struct vkrhip_ctx {
   DevBuf<float4> camera_view;
 
   // cull intermediates / outputs
-  uint32_t mask_words = 0;
-  uint64_t tiles_stride = 0;
-  DevBuf<uint32_t> masks;
   DevBuf<uint8_t> tvis;
   DevBuf<CompactionState> states;
   DevBuf<uint32_t> row_totals;  // survivors per count row, written by k_scan
-  // Per-frame accumulators: [counter block 0 | counter block 1 | tile counts], a
-  // counter block being [sharded counters | tie counters]. Frames alternate
-  // between the two counter blocks. The compaction kernels of a frame zero the
-  // other block and the tile counts they have consumed, so steady-state frames
-  // start without a fill; the flags below fall back to a fill whenever a frame
-  // ran without those kernels.
+  // Segment tables of the compaction: a segment is the stretch of candidates one
+  // classify block handled (at most 1024). Sized for the hierarchy in use.
+  DevBuf<uint32_t> stage;        // [max_views + 1][stage_stride] segment-local survivor lists
+  DevBuf<uint32_t> seg_counts;   // [max_views * 4 + 1][seg_stride]
+  DevBuf<uint32_t> seg_offsets;  // same shape, exclusive prefix
+  DevBuf<uint32_t> seg_first;    // [seg_stride]
+  uint64_t stage_stride = 0;
+  uint64_t seg_stride = 0;
+  uint64_t segments = 0;  // segments of the frame being enqueued
+  // Per-frame counters: two blocks of [sharded counters | tie counters]. Frames
+  // alternate between them; the scan kernel of a frame zeroes the other block,
+  // so steady-state frames start without a fill. block_clean falls back to a
+  // fill whenever a frame ran without that kernel.
   DevBuf<uint8_t> frame_zero;
   uint32_t cur_block = 0;
   bool block_clean[2] = {true, true};
-  bool tiles_clean = true;
   static constexpr size_t kCountersBytes = sizeof(uint32_t) * CNT_COUNT * STAT_SHARDS;
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
   static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes;
@@ -102,10 +105,6 @@ struct vkrhip_ctx {
   unsigned long long *ties() const {
     return reinterpret_cast<unsigned long long *>(counter_block(cur_block) + kCountersBytes);
   }
-  uint32_t *tile_counts() const {
-    return reinterpret_cast<uint32_t *>(frame_zero.p + 2u * kBlockBytes);
-  }
-  size_t tile_counts_bytes() const { return frame_zero.count - 2u * kBlockBytes; }
   DevBuf<uint64_t> tkey;
   DevBuf<uint32_t> visible;
   uint64_t visible_stride = 0;
@@ -296,13 +295,10 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->tie_eps, VKRHIP_MAX_VIEWS * 6));
     TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->camera_view, 4));
-    c->mask_words = (c->cfg.max_views + 31u) / 32u;
-    c->tiles_stride = (ceil_div(mc, CULL_TILE) + 3u) & ~(uint64_t)3u;  // rows are whole uint4s
-    TRY(dev_alloc(c, c->masks, (size_t)c->mask_words * mc));
+    c->stage_stride = mc;
+    TRY(dev_alloc(c, c->stage, (size_t)(c->cfg.max_views + 1u) * mc));
     TRY(dev_alloc(c, c->tvis, mc));
-    TRY(dev_alloc(c, c->frame_zero,
-                  2u * vkrhip_ctx::kBlockBytes +
-                      (size_t)(c->cfg.max_views * 4u + 1u) * c->tiles_stride * sizeof(uint32_t)));
+    TRY(dev_alloc(c, c->frame_zero, 2u * vkrhip_ctx::kBlockBytes));
     HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, c->frame_zero.count, c->stream));
     TRY(dev_alloc(c, c->tkey, mc));
     TRY(dev_alloc(c, c->states, VKRHIP_MAX_VIEWS));
@@ -352,7 +348,10 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->tie_eps);
   dev_free(c->required);
   dev_free(c->camera_view);
-  dev_free(c->masks);
+  dev_free(c->stage);
+  dev_free(c->seg_counts);
+  dev_free(c->seg_offsets);
+  dev_free(c->seg_first);
   dev_free(c->tvis);
   dev_free(c->frame_zero);
   dev_free(c->tkey);
@@ -626,16 +625,17 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.tie_eps = c->tie_eps.p;
   a.required = c->required.p;
   a.view = c->camera_view.p;
-  a.masks = c->masks.p;
   a.tvis = c->tvis.p;
   a.tkey = c->tkey.p;
   a.world_bounds = c->world_bounds.p;
-  a.tile_counts = c->tile_counts();
+  a.stage = c->stage.p;
+  a.seg_counts = c->seg_counts.p;
+  a.seg_first = c->seg_first.p;
   a.counters = c->counters();
   a.ties = c->ties();
   a.n = c->n_cand;
-  a.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
-  a.tiles_stride = c->tiles_stride;
+  a.stage_stride = c->stage_stride;
+  a.seg_stride = c->seg_stride;
   a.index_base = c->cfg.source_index_base;
   a.views = c->views;
   return a;
@@ -658,43 +658,79 @@ static int launch_transform(vkrhip_ctx *c) {
   return VKRHIP_OK;
 }
 
+// Grows the segment tables to hold `segments` columns (whole uint4s per row).
+static int ensure_segments(vkrhip_ctx *c, uint64_t segments) {
+  const uint64_t need = (segments + 3u) & ~(uint64_t)3u;
+  if (need <= c->seg_stride) return VKRHIP_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  dev_free(c->seg_counts);
+  dev_free(c->seg_offsets);
+  dev_free(c->seg_first);
+  c->seg_stride = 0;
+  const uint64_t stride = need + need / 4u;  // head room for a growing scene
+  const size_t rows = (size_t)c->cfg.max_views * 4u + 1u;
+  TRY(dev_alloc(c, c->seg_counts, rows * stride));
+  TRY(dev_alloc(c, c->seg_offsets, rows * stride));
+  TRY(dev_alloc(c, c->seg_first, stride));
+  c->seg_stride = stride & ~(uint64_t)3u;
+  return VKRHIP_OK;
+}
+
+// Blocks (= cull segments) the fused kernel launches for level l, and the rounds
+// of a tile each block walks: whole 1024-node tiles only for large levels, so
+// that small levels still give every CU several blocks.
+static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *rounds) {
+  const uint64_t begin = c->level_offsets[l], end = c->level_offsets[l + 1];
+  if (end == begin) return 0;
+  const uint64_t tiles = ceil_div(end, CULL_TILE) - begin / CULL_TILE;
+  *rounds = c->fused_rounds ? c->fused_rounds : (tiles >= 1024 ? 4u : tiles >= 512 ? 2u : 1u);
+  return tiles * (FUSED_ROUNDS / *rounds);
+}
+
 template <bool HAS_PARENT>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
                                  bool bounds_out) {
   const dim3 g(grid), b(FUSED_BLOCK);
+  const size_t lds = cull_shared_bytes(a.c.views);
   if (ties) {
     if (bounds_out)
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, true>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, true>), g, b, lds, c->stream, a);
     else
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, false>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, false>), g, b, lds, c->stream, a);
   } else {
     if (bounds_out)
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, true>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, true>), g, b, lds, c->stream, a);
     else
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, false>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, false>), g, b, lds, c->stream, a);
   }
 }
 
 // Transform and classify in one launch per level (candidate i <-> node i).
 static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
-  StageTimer timer(c, VKRHIP_TIMER_FUSED);
-  c->tiles_clean = false;
   const uint32_t levels = (uint32_t)c->level_offsets.size() - 1u;
+  uint64_t segments = 0;
+  for (uint32_t l = 0; l < levels; ++l) {
+    uint32_t rounds = 4;
+    segments += fused_level_grid(c, l, &rounds);
+  }
+  TRY(ensure_segments(c, segments));
+  StageTimer timer(c, VKRHIP_TIMER_FUSED);
   const bool ties = c->cfg.tie_epsilon > 0.f;
+  uint64_t seg_base = 0;
   for (uint32_t l = 0; l < levels; ++l) {
     FusedArgs a{};
+    const uint64_t grid = fused_level_grid(c, l, &a.rounds);
+    if (!grid) continue;
     a.t = transform_args(c, l);
     a.c = cull_args(c);
-    if (a.t.end == a.t.begin) continue;
-    const uint64_t tiles = ceil_div(a.t.end, CULL_TILE) - a.t.begin / CULL_TILE;
-    // enough blocks to give every CU several: whole tiles only for large levels
-    a.rounds = c->fused_rounds ? c->fused_rounds : (tiles >= 1024 ? 4u : tiles >= 512 ? 2u : 1u);
-    const unsigned grid = (unsigned)(tiles * (FUSED_ROUNDS / a.rounds));
+    a.seg_base = (uint32_t)seg_base;
     if (l == 0 || !c->parent.p)
-      launch_fused_variant<false>(c, a, grid, ties, bounds_out);
+      launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out);
     else
-      launch_fused_variant<true>(c, a, grid, ties, bounds_out);
+      launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out);
+    seg_base += grid;
   }
+  c->segments = segments;
   c->force_flags = 0;
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
@@ -704,49 +740,50 @@ template <bool IDENTITY>
 static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned grid, bool ties,
                                     bool bounds_out) {
   const dim3 g(grid), b(CULL_BLOCK);
+  const size_t lds = cull_shared_bytes(a.views);
   if (ties) {
     if (bounds_out)
-      hipLaunchKernelGGL((k_classify<IDENTITY, true, true>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_classify<IDENTITY, true, true>), g, b, lds, c->stream, a);
     else
-      hipLaunchKernelGGL((k_classify<IDENTITY, true, false>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_classify<IDENTITY, true, false>), g, b, lds, c->stream, a);
   } else {
     if (bounds_out)
-      hipLaunchKernelGGL((k_classify<IDENTITY, false, true>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_classify<IDENTITY, false, true>), g, b, lds, c->stream, a);
     else
-      hipLaunchKernelGGL((k_classify<IDENTITY, false, false>), g, b, 0, c->stream, a);
+      hipLaunchKernelGGL((k_classify<IDENTITY, false, false>), g, b, lds, c->stream, a);
   }
 }
 
 static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
+  c->segments = ceil_div(c->n_cand, CULL_TILE);
   if (!c->n_cand) return VKRHIP_OK;
+  TRY(ensure_segments(c, c->segments));
   StageTimer timer(c, VKRHIP_TIMER_CLASSIFY);
   const CullArgs a = cull_args(c);
-  c->tiles_clean = false;
-  const unsigned grid = (unsigned)ceil_div(c->n_cand, CULL_BLOCK);
   const bool ties = c->cfg.tie_epsilon > 0.f;
   if (c->node_identity)
-    launch_classify_variant<true>(c, a, grid, ties, bounds_out);
+    launch_classify_variant<true>(c, a, (unsigned)c->segments, ties, bounds_out);
   else
-    launch_classify_variant<false>(c, a, grid, ties, bounds_out);
+    launch_classify_variant<false>(c, a, (unsigned)c->segments, ties, bounds_out);
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
 
 static int launch_compaction(vkrhip_ctx *c) {
-  const uint64_t n = c->n_cand;
-  const uint64_t tiles = ceil_div(n, CULL_TILE);
-  if (!tiles) {  // nothing to compact: empty states, zero transparent rows (counters are zeroed)
+  const uint64_t segments = c->n_cand ? c->segments : 0;
+  if (!segments) {  // nothing to compact: empty states, zero transparent rows (counters are zeroed)
     HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
     return VKRHIP_OK;
   }
   {
     StageTimer timer(c, VKRHIP_TIMER_SCAN);
     ScanArgs s{};
-    s.tile_counts = c->tile_counts();
+    s.seg_counts = c->seg_counts.p;
+    s.seg_offsets = c->seg_offsets.p;
     s.row_totals = c->row_totals.p;
     s.counters = c->counters();
-    s.tiles = tiles;
-    s.tiles_stride = c->tiles_stride;
+    s.segments = segments;
+    s.seg_stride = c->seg_stride;
     s.views = c->views;
     s.transparent_capacity = c->tcap;
     s.host_hint = c->host_hint;
@@ -756,29 +793,29 @@ static int launch_compaction(vkrhip_ctx *c) {
     HIP_TRY(c, hipGetLastError());
     c->block_clean[c->cur_block ^ 1u] = true;
   }
-  if (tiles) {
+  {
     StageTimer timer(c, VKRHIP_TIMER_SCATTER);
-    ScatterArgs s{};
-    s.masks = c->masks.p;
-    s.cflags = c->cflags.p;
-    s.tvis = c->tvis.p;
-    s.tkey = c->tkey.p;
-    s.tile_offsets = c->tile_counts();
-    s.row_totals = c->row_totals.p;
-    s.states = c->states.p;
-    s.visible = c->visible.p;
-    s.keys = c->keys_a.p;
-    s.n = n;
-    s.mask_stride = std::max<uint64_t>(c->cfg.max_candidates, 1);
-    s.tiles_stride = c->tiles_stride;
-    s.visible_stride = c->visible_stride;
-    s.transparent_capacity = c->tcap;
-    s.index_base = c->cfg.source_index_base;
-    s.views = c->views;
-    s.partition_capacity = c->cfg.partition_capacity;
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)tiles), dim3(CULL_BLOCK), 0, c->stream, s);
+    GatherArgs g{};
+    g.stage = c->stage.p;
+    g.seg_offsets = c->seg_offsets.p;
+    g.seg_first = c->seg_first.p;
+    g.row_totals = c->row_totals.p;
+    g.tkey = c->tkey.p;
+    g.states = c->states.p;
+    g.visible = c->visible.p;
+    g.keys = c->keys_a.p;
+    g.segments = segments;
+    g.stage_stride = c->stage_stride;
+    g.seg_stride = c->seg_stride;
+    g.visible_stride = c->visible_stride;
+    g.transparent_capacity = c->tcap;
+    g.index_base = c->cfg.source_index_base;
+    g.views = c->views;
+    g.partition_capacity = c->cfg.partition_capacity;
+    const unsigned grid = (unsigned)ceil_div(segments, GATHER_BLOCK / 64);
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(GATHER_BLOCK), gather_shared_bytes(c->views),
+                       c->stream, g);
     HIP_TRY(c, hipGetLastError());
-    c->tiles_clean = true;  // every count this frame produced has been consumed and zeroed
   }
   return VKRHIP_OK;
 }
@@ -888,16 +925,12 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
   if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
   {
     StageTimer frame_timer(c, VKRHIP_TIMER_FRAME);
-    // this frame's counter block and the tile counts are normally already zero
-    // (cleared by the previous frame's compaction kernels)
+    // this frame's counter block is normally already zero (cleared by the
+    // previous frame's scan kernel)
     c->cur_block ^= 1u;
     if (!c->block_clean[c->cur_block])
       HIP_TRY(c, hipMemsetAsync(c->counter_block(c->cur_block), 0, vkrhip_ctx::kBlockBytes, c->stream));
     c->block_clean[c->cur_block] = false;
-    if (cull && !c->tiles_clean) {
-      HIP_TRY(c, hipMemsetAsync(c->tile_counts(), 0, c->tile_counts_bytes(), c->stream));
-      c->tiles_clean = true;
-    }
     // the fused kernel serves scenes that draw node i with candidate i
     const bool fused = cull && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
                        c->n_cand > 0 && c->n_cand <= c->n_nodes && c->level_offsets.size() > 1;
