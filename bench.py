@@ -46,18 +46,18 @@ WORKLOADS = {
 
 # Algorithmic HBM bytes per unit for each kernel of the frame:
 #   transform: local 64 + parent index 4 (non-root) + flags 1+1 + world 64
-#   classify : world 64 + sphere 16 + flags 4 in; view-mask words 4*W + visible byte 1 out
+#   classify : world 64 + sphere 16 + flags 4 in; visibility byte 1 out, plus 4 per
+#              surviving (instance, view) (the staged survivor index)
 #   fused    : both, minus the re-read of world (it is classified in registers)
-def kernel_bytes(name: str, n: int, depth: int, views: int) -> float:
-    words = (views + 31) // 32
+def kernel_bytes(name: str, n: int, depth: int, survivors: int) -> float:
     transform = 64 + 64 + 2 + (4 if depth > 1 else 0)
-    classify_in, classify_out = 64 + 16 + 4, 4 * words + 1
+    classify_in, classify_out = 64 + 16 + 4, 1
     if name == "transform":
         return n * transform
     if name == "classify":
-        return n * (classify_in + classify_out)
+        return n * (classify_in + classify_out) + 4 * survivors
     if name == "fused":
-        return n * (transform + classify_in - 64 + classify_out)
+        return n * (transform + classify_in - 64 + classify_out) + 4 * survivors
     raise KeyError(name)
 
 
@@ -214,7 +214,8 @@ def main() -> int:
     dom_ms, dom_n = timers[dominant]
     dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
     launches = 1 if dominant == "classify" else len(sc.level_offsets) - 1
-    alg_bytes = kernel_bytes(dominant, n, workload["depth"], views)
+    survivors = sum(st.visible_count for st in info.views) + info.transparent_draw_count
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors)
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     overridden = bool(args.instances) or any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes"))
     traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant])

@@ -14,10 +14,9 @@
 // yields descending keys with larger source index first among equal depths -
 // exactly descending order on the full 64-bit key - while only the 32 depth
 // bits have to be moved through the radix passes. Per 8-bit pass: per-tile
-// digit histogram -> exclusive scan over (digit, tile) -> stable scatter; a
-// single workgroup that keeps both key buffers in LDS (k_sort_small) takes over
-// when the count turns out to be small. All kernels read the count on the
-// device (no host round trip between cull and sort). Ranking inside a wave is a
+// digit histogram -> per-digit exclusive scan over the tiles -> stable scatter.
+// All kernels read the count on the device (no host round trip between cull
+// and sort). Ranking inside a wave is a
 // 64-wide match on the digit built from eight ballots, with per-wave running
 // digit counters in LDS.
 #pragma once
@@ -91,6 +90,7 @@ struct SortArgs {
   const uint64_t *keys_in;
   uint64_t *keys_out;
   uint32_t *hist;            // [digit][tiles_stride]
+  uint32_t *totals;          // [SORT_RADIX] keys per digit (this pass)
   const uint32_t *counters;  // CNT_TRANSPARENT
   uint32_t tiles_stride;
   uint32_t shift;
@@ -211,28 +211,9 @@ __device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *
   return true;
 }
 
-// Sort of keys[0, count) on bits [begin_shift, 64) by one workgroup, entirely in
-// LDS, result in `keys`. Does nothing above SMALL_KEYS keys (the multi-pass
-// kernels launched next to it then do the work).
-__global__ __launch_bounds__(SMALL_THREADS) void k_sort_small(uint64_t *keys,
-                                                              const uint32_t *counters,
-                                                              uint32_t begin_shift) {
-  __shared__ SmallSortShared s;
-  const uint32_t count = counters[CNT_TRANSPARENT];
-  if (count == 0 || count > SMALL_KEYS) return;
-  const uint32_t t = threadIdx.x;
-  for (uint32_t k = t; k < count; k += SMALL_THREADS) s.keys[0][k] = keys[k];
-  uint32_t cur = 0;
-  for (uint32_t shift = begin_shift; shift < 64u; shift += 8u)
-    if (block_radix_pass(s.keys[cur], s.keys[cur ^ 1u], count, shift, s)) cur ^= 1u;
-  __syncthreads();
-  for (uint32_t k = t; k < count; k += SMALL_THREADS) keys[k] = s.keys[cur][k];
-}
-
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
   __shared__ uint32_t s_hist[SORT_RADIX];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
-  if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -250,32 +231,32 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
   }
 }
 
-// Exclusive scan over hist[digit][0..tiles) in digit-major order, one block:
-// four threads per digit, each owning a quarter of the digit's tile row. A
-// thread sums its run, one block-wide scan of the 1024 sums gives its starting
-// offset, and a second sweep writes the exclusive prefix in place.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_radix_scan(SortArgs a) {
-  static_assert(SCAN_BLOCK == SORT_RADIX * 4, "four threads per digit");
-  __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+// Exclusive scan of every digit's tile row, one block per digit: thread t owns a
+// run of consecutive tiles, sums it, a block-wide scan of the 256 sums gives its
+// start, and a second sweep writes the row-local exclusive prefix in place. The
+// digit's total goes to totals[digit]; the scatter kernel adds the totals of the
+// smaller digits.
+__global__ __launch_bounds__(SORT_BLOCK) void k_radix_scan(SortArgs a) {
+  __shared__ uint32_t s_wave[SORT_BLOCK / 64];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
-  if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
-  const uint32_t digit = threadIdx.x >> 2, part = threadIdx.x & 3u;
-  const uint32_t chunk = (tiles + 3u) / 4u;
-  const uint32_t begin = min(part * chunk, tiles);
+  const uint32_t digit = blockIdx.x;
+  const uint32_t chunk = (tiles + SORT_BLOCK - 1) / SORT_BLOCK;
+  const uint32_t begin = min(threadIdx.x * chunk, tiles);
   const uint32_t end = min(begin + chunk, tiles);
   uint32_t *row = a.hist + (uint64_t)digit * a.tiles_stride;
   uint32_t sum = 0u;
-#pragma unroll 8
+#pragma unroll 4
   for (uint32_t k = begin; k < end; ++k) sum += row[k];
   uint32_t total;
   uint32_t run = block_exclusive_scan(sum, s_wave, &total);
-#pragma unroll 8
+#pragma unroll 4
   for (uint32_t k = begin; k < end; ++k) {
     const uint32_t c = row[k];
     row[k] = run;
     run += c;
   }
+  if (threadIdx.x == 0) a.totals[digit] = total;
 }
 
 // Stable scatter. Wave w of the block owns keys [w*512, w*512+512) of the tile
@@ -284,17 +265,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_radix_scan(SortArgs a) {
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
   __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave digit counts, then bases
   __shared__ uint32_t s_base[SORT_RADIX];      // global base of (digit, tile)
+  __shared__ uint32_t s_wave[SORT_BLOCK / 64];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
-  if (count <= SMALL_KEYS) return;
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
   const uint32_t wave = t >> 6;
   const uint32_t lane = t & 63u;
+  if (blockIdx.x >= tiles) return;  // block-uniform
+  // keys with smaller digits come first: exclusive scan of the digit totals
+  uint32_t all_keys;
+  const uint32_t digit_base = block_exclusive_scan(a.totals[t], s_wave, &all_keys);
 
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     __syncthreads();  // previous tile's readers are done
     for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
-    s_base[t] = a.hist[t * a.tiles_stride + tile];
+    s_base[t] = digit_base + a.hist[t * a.tiles_stride + tile];
     __syncthreads();
 
     uint64_t key[SORT_ITEMS];

@@ -564,7 +564,7 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
     TRY(dev_alloc(c, c->out_keys, tcap));
     TRY(dev_alloc(c, c->out_source, tcap));
     c->sort_tiles_stride = (uint32_t)ceil_div(tcap, SORT_TILE);
-    TRY(dev_alloc(c, c->hist, (size_t)SORT_RADIX * c->sort_tiles_stride));
+    TRY(dev_alloc(c, c->hist, (size_t)SORT_RADIX * c->sort_tiles_stride + SORT_RADIX));
     TRY(dev_alloc(c, c->draws, tcap * 3));
     TRY(dev_alloc(c, c->instances, tcap * 5));
     c->tcap = tcap;
@@ -842,10 +842,9 @@ static int launch_transparent(vkrhip_ctx *c) {
   // either says the count is small, one launch ranks every key against all
   // others and emits the rows (k_rank_emit). Otherwise the multi-pass radix
   // kernels run on the depth bits (the low word is already ordered by
-  // construction), next to a single-workgroup LDS sort that takes over when the
-  // count turns out small after all, and a separate emission launch follows.
-  // Every kernel re-checks the real count, so a wrong guess costs time, never
-  // correctness.
+  // construction) and a separate emission launch follows. Every kernel reads
+  // the real count on the device and both paths sort any count, so a wrong
+  // guess costs time, never correctness.
   const uint32_t hint = *reinterpret_cast<volatile uint32_t *>(c->host_hint);
   uint64_t expected = cap;
   if (hint != 0u) expected = std::min<uint64_t>(cap, (uint64_t)(hint - 1u) * 5u / 4u + 256u);
@@ -860,8 +859,6 @@ static int launch_transparent(vkrhip_ctx *c) {
   }
   {
     StageTimer timer(c, VKRHIP_TIMER_SORT);
-    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SMALL_THREADS), 0, c->stream, c->keys_a.p,
-                       c->counters(), 32u);
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
     bool in_a = true;
     for (uint32_t shift = 32; shift < 64; shift += 8) {  // four passes end in keys_a again
@@ -869,11 +866,12 @@ static int launch_transparent(vkrhip_ctx *c) {
       s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
       s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
       s.hist = c->hist.p;
+      s.totals = c->hist.p + (size_t)SORT_RADIX * c->sort_tiles_stride;
       s.counters = c->counters();
       s.tiles_stride = c->sort_tiles_stride;
       s.shift = shift;
       hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
+      hipLaunchKernelGGL(k_radix_scan, dim3(SORT_RADIX), dim3(SORT_BLOCK), 0, c->stream, s);
       hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
       in_a = !in_a;
     }
