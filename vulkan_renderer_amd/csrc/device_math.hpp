@@ -92,12 +92,19 @@ __host__ __device__ __forceinline__ float mat4_mul_vec4_z(const Mat4 &m, float x
   return (m.c[0].z * x + m.c[1].z * y) + (m.c[2].z * z + m.c[3].z * w);
 }
 
-// max(max(|col0|, |col1|), |col2|), lib/src/renderer/vkr_visibility.c:42-46
+// max(max(|col0|, |col1|), |col2|), lib/src/renderer/vkr_visibility.c:42-46.
+// The reference takes three square roots and then the maxima; here the maxima
+// are taken on the squared lengths and one root follows. The result has the
+// same bits: a correctly rounded square root is monotonic, so every `a > b`
+// selection picks an operand whose root is the value the reference selects
+// (roots that round to the same float are the same float; a NaN operand makes
+// both forms fall through to the other operand; zeros of either sign compare
+// equal in both forms).
 __host__ __device__ __forceinline__ float max_basis_length(const Mat4 &m) {
-  const float l0 = length3(m.c[0].x, m.c[0].y, m.c[0].z);
-  const float l1 = length3(m.c[1].x, m.c[1].y, m.c[1].z);
-  const float l2 = length3(m.c[2].x, m.c[2].y, m.c[2].z);
-  return max_sel(max_sel(l0, l1), l2);
+  const float d0 = dot3(m.c[0].x, m.c[0].y, m.c[0].z, m.c[0].x, m.c[0].y, m.c[0].z);
+  const float d1 = dot3(m.c[1].x, m.c[1].y, m.c[1].z, m.c[1].x, m.c[1].y, m.c[1].z);
+  const float d2 = dot3(m.c[2].x, m.c[2].y, m.c[2].z, m.c[2].x, m.c[2].y, m.c[2].z);
+  return sqrt_rn(max_sel(max_sel(d0, d1), d2));
 }
 
 // vkr_quat_to_mat4, lib/src/math/mat.h:1538-1560

@@ -287,8 +287,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       }
       if (valid && col == 0) a.t.flags[node] = (uint8_t)hd.f[r];
       s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
-      const unsigned long long m = __ballot(did_update && col == 0);
-      updated_here += (uint32_t)__popcll(m);
+      updated_here += (did_update && col == 0) ? 1u : 0u;  // per lane; summed when the block ends
     }
     __syncthreads();
 
@@ -306,7 +305,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
                                                    hd.ls, hd.cf)
               << (8 * round);
   }
-  if ((t & 63u) == 0 && updated_here) atomicAdd(&s_updated, updated_here);
+  {
+    const uint32_t wave_updates = wave_inclusive_scan(updated_here);
+    if ((t & 63u) == 63u && wave_updates) atomicAdd(&s_updated, wave_updates);
+  }
   segment_finish<TIES>(a.c, s, seg, tile_base + lo, lo, packed);
   if (t == 0 && s_updated) atomicAdd(a.t.counters + stat_shard() + CNT_NODES_UPDATED, s_updated);
 }
