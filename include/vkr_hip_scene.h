@@ -65,6 +65,8 @@ extern "C" {
 #define VKRHIP_STAGE_TRANSPARENT 0x4u /* key, sort, emit: application.h:573-587,940-944 */
 #define VKRHIP_STAGE_CANDIDATES 0x8u  /* 144-byte VkrWorldDrawCandidate rows, application.h:617-662 */
 #define VKRHIP_STAGE_WORLD_BOUNDS 0x10u /* instance world spheres, vkr_mesh_manager.c:315-337 */
+#define VKRHIP_STAGE_PACK 0x20u   /* vkr_vk_pack_gpu_candidates, vkr_vulkan_draws.c:344-428 */
+#define VKRHIP_STAGE_ENCODE 0x40u /* visible rows + indirect commands, deferred.slang:379-420 */
 #define VKRHIP_STAGE_ALL 0x7u
 
 typedef struct vkrhip_ctx vkrhip_ctx;
@@ -113,6 +115,13 @@ typedef struct vkrhip_frame_info {
   uint32_t nodes_updated;                     /* length of the render-dirty list, vkr_scene_system.c:1335 */
   uint32_t view_count;
   uint32_t reserved;
+  /* vkr_vk_pack_gpu_candidates counters (zero without a publication): rows packed,
+   * omitted for an unpublished geometry / material, rejected for a submesh
+   * outside its geometry (the reference fails the frame when that is non-zero) */
+  uint32_t packed_count;
+  uint32_t unpublished_geometry_count;
+  uint32_t unpublished_material_count;
+  uint32_t invalid_submesh_count;
   uint64_t near_plane_ties[VKRHIP_MAX_VIEWS];
   vkrhip_compaction_state views[VKRHIP_MAX_VIEWS];
 } vkrhip_frame_info;
@@ -133,7 +142,38 @@ typedef struct vkrhip_device_outputs {
   const void *gpu_candidates;         /* n x VkrWorldDrawCandidate (144 B) when STAGE_CANDIDATES ran */
   const float *world_bounds;          /* n x (cx,cy,cz,r) when STAGE_WORLD_BOUNDS ran */
   const uint32_t *device_counts;      /* device copy of the scalar counters */
+  const void *packed_rows;            /* packed_count x VkrGpuCandidateDrawRow (48 B) when STAGE_PACK ran */
+  const void *packed_instances;       /* packed_count x VkrInstanceDataGPU (80 B) */
+  const void *visible_rows;           /* view v at v*visible_stride: VkrGpuVisibleDrawRow (32 B)
+                                         per visible slot when STAGE_ENCODE ran */
+  const void *commands;               /* (view*4+bucket)*partition_capacity + local: 20-byte
+                                         indirect commands; null when partition_capacity is 0 */
 } vkrhip_device_outputs;
+
+/* Backend publication state, flattened (VkrVulkanPublishedGeometry,
+ * VkrVulkanSubmeshRange, VkrVulkanPublishedMaterial:
+ * lib/src/renderer/vulkan/vkr_vulkan_internal.h:838-870). Entry k describes
+ * handle id k + 1. */
+typedef struct vkrhip_geometry_entry {
+  uint32_t generation;     /* handle.generation of the published record */
+  uint32_t resolvable;     /* live && pending_initialization_count == 0 */
+  uint32_t first_index;    /* gpu_row.first_index */
+  uint32_t submesh_count;
+  uint32_t submesh_offset; /* first entry of this geometry in the submesh array */
+  uint32_t reserved[3];
+} vkrhip_geometry_entry;
+typedef struct vkrhip_submesh_range {
+  uint32_t first_index;
+  uint32_t index_count;
+  int32_t vertex_offset;
+  uint32_t reserved;
+} vkrhip_submesh_range;
+typedef struct vkrhip_material_entry {
+  uint32_t generation;
+  uint32_t live;
+  uint32_t slot_index;
+  uint32_t reserved;
+} vkrhip_material_entry;
 
 /* ---- lifetime --------------------------------------------------------- */
 int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx);
@@ -184,6 +224,17 @@ int vkrhip_set_candidates(vkrhip_ctx *ctx, uint64_t n, const uint32_t *node,
 int vkrhip_set_views(vkrhip_ctx *ctx, uint32_t views, const float *planes,
                      const uint32_t *required_flags, const float *camera_view);
 
+/* ---- backend publication: the tables vkr_vk_pack_gpu_candidates resolves
+ * handles against (lib/src/renderer/vulkan/vkr_vulkan_draws.c:321-342). Call
+ * after vkrhip_set_candidates and again whenever the tables or the candidates
+ * change. From then on rows that do not resolve are in no GPU view and the
+ * visible lists hold PACKED row indices (the cull of the reference runs on the
+ * packed rows); source_index_base does not apply to them. */
+int vkrhip_set_publication(vkrhip_ctx *ctx, const vkrhip_geometry_entry *geometries,
+                           uint32_t geometry_capacity, const vkrhip_submesh_range *submeshes,
+                           uint32_t submesh_count, const vkrhip_material_entry *materials,
+                           uint32_t material_capacity);
+
 /* ---- the frame ------------------------------------------------------------ */
 /* Enqueues the selected stages on the context's stream and returns without
  * waiting. */
@@ -202,6 +253,11 @@ int vkrhip_read_transparent_visible(vkrhip_ctx *ctx, uint64_t first, uint64_t co
 int vkrhip_read_transparent(vkrhip_ctx *ctx, uint64_t count, void *draws48, void *instances80,
                             uint64_t *keys, uint32_t *source);
 int vkrhip_read_candidates(vkrhip_ctx *ctx, uint64_t first, uint64_t count, void *rows144);
+int vkrhip_read_packed(vkrhip_ctx *ctx, uint64_t count, void *rows48, void *instances80);
+int vkrhip_read_visible_rows(vkrhip_ctx *ctx, uint32_t view, uint64_t count, void *rows32);
+/* `count` commands of (view, bucket), starting at local index 0 */
+int vkrhip_read_commands(vkrhip_ctx *ctx, uint32_t view, uint32_t bucket, uint64_t count,
+                         void *commands20);
 int vkrhip_read_world_bounds(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out4);
 int vkrhip_read_candidate_prep(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
                                float *sphere4, uint32_t *flags_bucket);

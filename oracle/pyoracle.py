@@ -88,6 +88,38 @@ VISIBLE_ROW_DT = np.dtype(
         "itemsize": 32,
     }
 )
+GEOMETRY_DT = np.dtype(
+    {
+        "names": ["generation", "resolvable", "first_index", "submesh_count", "submesh_offset"],
+        "formats": ["<u4"] * 5,
+        "offsets": [0, 4, 8, 12, 16],
+        "itemsize": 32,
+    }
+)
+SUBMESH_DT = np.dtype(
+    {
+        "names": ["first_index", "index_count", "vertex_offset"],
+        "formats": ["<u4", "<u4", "<i4"],
+        "offsets": [0, 4, 8],
+        "itemsize": 16,
+    }
+)
+MATERIAL_DT = np.dtype(
+    {
+        "names": ["generation", "live", "slot_index"],
+        "formats": ["<u4"] * 3,
+        "offsets": [0, 4, 8],
+        "itemsize": 16,
+    }
+)
+COMMAND_DT = np.dtype(
+    {
+        "names": ["index_count", "instance_count", "first_index", "vertex_offset", "first_instance"],
+        "formats": ["<u4", "<u4", "<u4", "<i4", "<u4"],
+        "offsets": [0, 4, 8, 12, 16],
+        "itemsize": 20,
+    }
+)
 
 
 def build(force: bool = False) -> None:
@@ -357,6 +389,37 @@ class Oracle:
         st = np.ascontiguousarray(state)
         self.lib.vko_encode_visible_rows(rows.ctypes.data, _u32(visible), st.ctypes.data,
                                          out.ctypes.data)
+        return out
+
+    def pack_gpu_candidates(self, candidates, geometries, submeshes, materials):
+        """vkr_vk_pack_gpu_candidates. Returns (ok, rows48, instances80, packed_source, counts4)."""
+        c = np.ascontiguousarray(candidates)
+        g = np.ascontiguousarray(geometries, dtype=GEOMETRY_DT)
+        sm = np.ascontiguousarray(submeshes, dtype=SUBMESH_DT)
+        m = np.ascontiguousarray(materials, dtype=MATERIAL_DT)
+        n = c.shape[0]
+        rows = np.zeros(max(n, 1), GPU_ROW_DT)
+        inst = np.zeros(max(n, 1), INSTANCE_DT)
+        src = np.zeros(max(n, 1), np.uint32)
+        counts = np.zeros(4, np.uint32)
+        self.lib.vko_pack_gpu_candidates.restype = C.c_int
+        ok = self.lib.vko_pack_gpu_candidates(
+            C.c_void_p(c.ctypes.data), C.c_uint32(n), C.c_void_p(g.ctypes.data),
+            C.c_uint32(g.shape[0]), C.c_void_p(sm.ctypes.data), C.c_void_p(m.ctypes.data),
+            C.c_uint32(m.shape[0]), C.c_void_p(rows.ctypes.data), C.c_void_p(inst.ctypes.data),
+            C.c_void_p(src.ctypes.data), C.c_void_p(counts.ctypes.data))
+        k = int(counts[0])
+        return bool(ok), rows[:k], inst[:k], src[:k], counts
+
+    def encode_commands(self, rows, visible, state, view, partition_capacity, views):
+        """Indirect commands of one view into a (views*4*partition,) command array."""
+        rows = np.ascontiguousarray(rows)
+        out = np.zeros(views * 4 * partition_capacity, COMMAND_DT)
+        st = np.ascontiguousarray(state)
+        vis = _u32(visible)
+        self.lib.vko_encode_commands(
+            C.c_void_p(rows.ctypes.data), C.c_void_p(vis.ctypes.data), C.c_void_p(st.ctypes.data),
+            C.c_uint32(view), C.c_uint32(partition_capacity), C.c_void_p(out.ctypes.data))
         return out
 
     def candidate_epoch(self, candidates):

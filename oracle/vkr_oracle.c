@@ -769,6 +769,82 @@ void vko_multiview_cull_flat(const float *world16, const uint32_t *node, const f
                      states, visible, near_plane_ties, world16, node);
 }
 
+int vko_pack_gpu_candidates(const vko_world_candidate *source, uint32_t count,
+                            const vko_geometry_entry *geometries, uint32_t geometry_capacity,
+                            const vko_submesh_range *submeshes,
+                            const vko_material_entry *materials, uint32_t material_capacity,
+                            vko_gpu_candidate_row *rows, vko_instance_data *instances,
+                            uint32_t *packed_source, uint32_t *counts4) {
+  uint32_t packed = 0, no_geometry = 0, no_material = 0, bad_submesh = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    const vko_world_candidate *c = &source[i];
+    /* vkr_vk_resolve_geometry / _material, vkr_vulkan_draws.c:321-342 */
+    const vko_geometry_entry *g = NULL;
+    if (c->geometry.id != 0u && c->geometry.id <= geometry_capacity) {
+      const vko_geometry_entry *e = &geometries[c->geometry.id - 1u];
+      if (e->resolvable && e->generation == c->geometry.generation)
+        g = e;
+    }
+    const vko_material_entry *m = NULL;
+    if (c->material.id != 0u && c->material.id <= material_capacity) {
+      const vko_material_entry *e = &materials[c->material.id - 1u];
+      if (e->live && e->generation == c->material.generation)
+        m = e;
+    }
+    if (!g) {
+      no_geometry++;
+      continue;
+    }
+    if (!m) {
+      no_material++;
+      continue;
+    }
+    if (c->submesh_index >= g->submesh_count) {
+      bad_submesh++;
+      continue;
+    }
+    const vko_submesh_range *sub = &submeshes[g->submesh_offset + c->submesh_index];
+    vko_gpu_candidate_row *r = &rows[packed];
+    r->geometry_index = c->geometry.id - 1u;
+    r->material_index = m->slot_index;
+    r->instance_index = packed;
+    r->first_index = g->first_index + sub->first_index;
+    r->index_count = sub->index_count;
+    r->vertex_offset = sub->vertex_offset;
+    r->state_bucket = c->state_bucket;
+    r->flags = c->flags;
+    memcpy(r->local_bounding_sphere, c->local_bounding_sphere, 16);
+    instances[packed] = c->instance;
+    if (packed_source)
+      packed_source[packed] = i;
+    packed++;
+  }
+  counts4[0] = packed;
+  counts4[1] = no_geometry;
+  counts4[2] = no_material;
+  counts4[3] = bad_submesh;
+  return bad_submesh ? 0 : 1;
+}
+
+void vko_encode_commands(const vko_gpu_candidate_row *rows, const uint32_t *visible,
+                         const vko_compaction_state *state, uint32_t view,
+                         uint32_t partition_capacity, vko_indirect_command *commands) {
+  for (uint32_t b = 0; b < VKO_BUCKET_COUNT; ++b) {
+    const uint32_t off = state->execution_ranges[b][0];
+    const uint32_t cnt = state->execution_ranges[b][1];
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const vko_gpu_candidate_row *c = &rows[visible[off + k]];
+      vko_indirect_command *o =
+          &commands[((uint64_t)view * VKO_BUCKET_COUNT + b) * partition_capacity + k];
+      o->index_count = c->index_count;
+      o->instance_count = 1u;
+      o->first_index = c->first_index;
+      o->vertex_offset = c->vertex_offset;
+      o->first_instance = 0u;
+    }
+  }
+}
+
 void vko_encode_visible_rows(const vko_gpu_candidate_row *rows, const uint32_t *visible,
                              const vko_compaction_state *state, vko_gpu_visible_row *out) {
   for (uint32_t b = 0; b < VKO_BUCKET_COUNT; ++b) {

@@ -292,6 +292,52 @@ void vko_multiview_cull_flat(const float *world16, const uint32_t *node,
                              uint64_t *near_plane_ties);
 
 /* Encode (deferred.slang:379-420) in the canonical order. */
+/* Backend publication tables flattened to POD (VkrVulkanPublishedGeometry /
+ * VkrVulkanSubmeshRange / VkrVulkanPublishedMaterial,
+ * lib/src/renderer/vulkan/vkr_vulkan_internal.h:838-870). */
+typedef struct vko_geometry_entry {
+  uint32_t generation;     /* handle.generation of the published record */
+  uint32_t resolvable;     /* live && pending_initialization_count == 0 */
+  uint32_t first_index;    /* gpu_row.first_index */
+  uint32_t submesh_count;
+  uint32_t submesh_offset; /* first entry in the submesh array */
+  uint32_t pad[3];
+} vko_geometry_entry;
+typedef struct vko_submesh_range {
+  uint32_t first_index;
+  uint32_t index_count;
+  int32_t vertex_offset;
+  uint32_t pad;
+} vko_submesh_range;
+typedef struct vko_material_entry {
+  uint32_t generation;
+  uint32_t live;
+  uint32_t slot_index;
+  uint32_t pad;
+} vko_material_entry;
+/* VkrVkIndirectCommand, deferred.slang:21-28 (20 B) */
+typedef struct vko_indirect_command {
+  uint32_t index_count;
+  uint32_t instance_count;
+  uint32_t first_index;
+  int32_t vertex_offset;
+  uint32_t first_instance;
+} vko_indirect_command;
+
+/* vkr_vk_pack_gpu_candidates, lib/src/renderer/vulkan/vkr_vulkan_draws.c:344-428.
+ * counts = {packed, unpublished geometry, unpublished material, invalid submesh};
+ * packed_source[k] = candidate index of packed row k. Returns 0 when the
+ * reference would reject the frame (a submesh outside its geometry). */
+int vko_pack_gpu_candidates(const vko_world_candidate *source, uint32_t count,
+                            const vko_geometry_entry *geometries, uint32_t geometry_capacity,
+                            const vko_submesh_range *submeshes,
+                            const vko_material_entry *materials, uint32_t material_capacity,
+                            vko_gpu_candidate_row *rows, vko_instance_data *instances,
+                            uint32_t *packed_source, uint32_t *counts4);
+/* the indirect commands of vk_gpu_draw_encode, deferred.slang:411-419 */
+void vko_encode_commands(const vko_gpu_candidate_row *rows, const uint32_t *visible,
+                         const vko_compaction_state *state, uint32_t view,
+                         uint32_t partition_capacity, vko_indirect_command *commands);
 void vko_encode_visible_rows(const vko_gpu_candidate_row *rows, const uint32_t *visible,
                              const vko_compaction_state *state, vko_gpu_visible_row *out);
 

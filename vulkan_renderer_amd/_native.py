@@ -25,6 +25,7 @@ ALPHA_OPAQUE, ALPHA_CUTOUT, ALPHA_BLEND = 0, 1, 2
 
 STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT = 0x1, 0x2, 0x4
 STAGE_CANDIDATES, STAGE_WORLD_BOUNDS = 0x8, 0x10
+STAGE_PACK, STAGE_ENCODE = 0x20, 0x40
 STAGE_ALL = 0x7
 
 TIMER_NAMES = ["transform", "classify", "fused", "scan", "scatter", "sort", "emit",
@@ -37,7 +38,8 @@ EXPORTED_SYMBOLS = [
     "vkrhip_frame", "vkrhip_get_frame_info", "vkrhip_get_device_outputs", "vkrhip_read_world",
     "vkrhip_read_locals", "vkrhip_read_node_flags", "vkrhip_read_visible",
     "vkrhip_read_transparent_visible", "vkrhip_read_transparent", "vkrhip_read_candidates",
-    "vkrhip_read_world_bounds", "vkrhip_read_candidate_prep", "vkrhip_set_profiling",
+    "vkrhip_read_world_bounds", "vkrhip_read_candidate_prep", "vkrhip_set_publication",
+    "vkrhip_read_packed", "vkrhip_read_visible_rows", "vkrhip_read_commands", "vkrhip_set_profiling",
     "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize",
@@ -88,6 +90,10 @@ class FrameInfo(C.Structure):
         ("nodes_updated", C.c_uint32),
         ("view_count", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("packed_count", C.c_uint32),
+        ("unpublished_geometry_count", C.c_uint32),
+        ("unpublished_material_count", C.c_uint32),
+        ("invalid_submesh_count", C.c_uint32),
         ("near_plane_ties", C.c_uint64 * MAX_VIEWS),
         ("views", CompactionState * MAX_VIEWS),
     ]
@@ -107,6 +113,10 @@ class DeviceOutputs(C.Structure):
         ("gpu_candidates", C.c_void_p),
         ("world_bounds", C.c_void_p),
         ("device_counts", C.c_void_p),
+        ("packed_rows", C.c_void_p),
+        ("packed_instances", C.c_void_p),
+        ("visible_rows", C.c_void_p),
+        ("commands", C.c_void_p),
     ]
 
 
@@ -157,6 +167,10 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_read_candidates.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_world_bounds.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_candidate_prep.argtypes = [vp, u64, u64, vp, vp]
+    L.vkrhip_set_publication.argtypes = [vp, vp, u32, vp, u32, vp, u32]
+    L.vkrhip_read_packed.argtypes = [vp, u64, vp, vp]
+    L.vkrhip_read_visible_rows.argtypes = [vp, u32, u64, vp]
+    L.vkrhip_read_commands.argtypes = [vp, u32, u32, u64, vp]
     L.vkrhip_set_profiling.argtypes = [vp, u32]
     L.vkrhip_get_timers.argtypes = [vp, vp, vp, C.c_int]
     L.vkrhip_merge_runs.argtypes = [vp, u32, vp, vp, vp]

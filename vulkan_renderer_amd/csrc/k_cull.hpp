@@ -47,6 +47,7 @@ constexpr uint32_t CF_REF_MASK = 0x7u;
 constexpr uint32_t CF_BUCKET_SHIFT = 4u;      // bits 4..7 state bucket
 constexpr uint32_t CF_BLEND = 0x100u;         // world_transparent
 constexpr uint32_t CF_TRANSMISSIVE = 0x200u;
+constexpr uint32_t CF_UNPUBLISHED = 0x400u;   // omitted by the backend pack: in no GPU view
 
 // device counters (uint32)
 enum : int {
@@ -242,7 +243,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     const uint32_t vend = min(a.views, (w + 1u) * 32u);
     for (uint32_t v = w * 32u; v < vend; ++v) {
       const uint32_t req = required[v];
-      bool pass = valid && bucket < 4u && (cf & req) == req;
+      bool pass = valid && bucket < 4u && !(cf & CF_UNPUBLISHED) && (cf & req) == req;
       bool tie = false;
       if (pass && bounds_valid) {
         const uniform_ptr<float> vp = planes + v * 24u;
@@ -615,6 +616,7 @@ struct GatherArgs {
   const uint32_t *seg_first;
   const uint32_t *row_totals;
   const uint64_t *tkey;
+  const uint32_t *remap;    // candidate -> packed row index when a publication is set, else null
   CompactionState *states;  // written by block 0
   uint32_t *visible;        // [view][visible_stride]
   uint64_t *keys;           // compacted sort keys of the visible blend rows
@@ -714,7 +716,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
     const uint32_t k = e - e_start[lo];
     const uint32_t v = lo >> 2;
     const uint32_t idx = a.stage[(uint64_t)v * a.stage_stride + e_src[lo] + k];
-    a.visible[(uint64_t)v * a.visible_stride + e_dst[lo] + k] = (uint32_t)(a.index_base + idx);
+    a.visible[(uint64_t)v * a.visible_stride + e_dst[lo] + k] =
+        a.remap ? a.remap[idx] : (uint32_t)(a.index_base + idx);
   }
   for (uint32_t k = lane; k < t_count; k += 64u) {
     const uint64_t pos = (uint64_t)t_offset + k;

@@ -18,6 +18,7 @@
 #include "device_math.hpp"
 #include "k_cull.hpp"
 #include "k_fused.hpp"
+#include "k_pack.hpp"
 #include "k_sort.hpp"
 #include "k_transform.hpp"
 
@@ -110,6 +111,22 @@ struct vkrhip_ctx {
   uint64_t visible_stride = 0;
   DevBuf<float4> world_bounds;
   DevBuf<uint4> cand_rows;
+
+  // backend pack / encode (allocated when a publication is set / the stage first runs)
+  bool published = false;
+  DevBuf<GeometryEntry> pub_geometries;
+  DevBuf<SubmeshRange> pub_submeshes;
+  DevBuf<MaterialEntry> pub_materials;
+  DevBuf<uint8_t> pack_status;
+  DevBuf<uint32_t> packed_index;
+  DevBuf<uint4> pack_a;
+  DevBuf<int32_t> pack_vo;
+  DevBuf<uint32_t> pack_counts;  // 4 words
+  uint32_t pack_counts_host[4] = {0, 0, 0, 0};
+  DevBuf<uint4> packed_rows;
+  DevBuf<float4> packed_instances;
+  DevBuf<uint4> visible_rows;
+  DevBuf<uint32_t> commands;
 
   // transparent
   DevBuf<uint64_t> keys_a, keys_b, out_keys;
@@ -349,6 +366,18 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->required);
   dev_free(c->camera_view);
   dev_free(c->stage);
+  dev_free(c->pub_geometries);
+  dev_free(c->pub_submeshes);
+  dev_free(c->pub_materials);
+  dev_free(c->pack_status);
+  dev_free(c->packed_index);
+  dev_free(c->pack_a);
+  dev_free(c->pack_vo);
+  dev_free(c->pack_counts);
+  dev_free(c->packed_rows);
+  dev_free(c->packed_instances);
+  dev_free(c->visible_rows);
+  dev_free(c->commands);
   dev_free(c->seg_counts);
   dev_free(c->seg_offsets);
   dev_free(c->seg_first);
@@ -528,6 +557,7 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
   c->n_cand = n;
   c->node_identity = node == nullptr;
   c->blend_rows = blend;
+  c->published = false;  // the candidate words are rebuilt below; vkrhip_set_publication must follow
   if (n) {
     if (node) {
       TRY(dev_alloc(c, c->node, c->cfg.max_candidates));
@@ -594,7 +624,118 @@ int vkrhip_set_views(vkrhip_ctx *c, uint32_t views, const float *planes,
   return VKRHIP_OK;
 }
 
+int vkrhip_set_publication(vkrhip_ctx *c, const vkrhip_geometry_entry *geometries,
+                           uint32_t geometry_capacity, const vkrhip_submesh_range *submeshes,
+                           uint32_t submesh_count, const vkrhip_material_entry *materials,
+                           uint32_t material_capacity) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if ((geometry_capacity && !geometries) || (submesh_count && !submeshes) ||
+      (material_capacity && !materials))
+    return fail(c, VKRHIP_ERR_ARG, "null publication table");
+  static_assert(sizeof(vkrhip_geometry_entry) == sizeof(GeometryEntry) &&
+                    sizeof(vkrhip_submesh_range) == sizeof(SubmeshRange) &&
+                    sizeof(vkrhip_material_entry) == sizeof(MaterialEntry),
+                "publication table ABI");
+  for (uint32_t g = 0; g < geometry_capacity; ++g)
+    if ((uint64_t)geometries[g].submesh_offset + geometries[g].submesh_count > submesh_count)
+      return fail(c, VKRHIP_ERR_ARG, "geometry %u names submeshes beyond the submesh table", g + 1u);
+  TRY(bind_device(c));
+  const uint64_t mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
+  TRY(dev_alloc(c, c->pub_geometries, std::max<uint32_t>(geometry_capacity, 1)));
+  TRY(dev_alloc(c, c->pub_submeshes, std::max<uint32_t>(submesh_count, 1)));
+  TRY(dev_alloc(c, c->pub_materials, std::max<uint32_t>(material_capacity, 1)));
+  if (!c->pack_status.p) {
+    TRY(dev_alloc(c, c->pack_status, mc));
+    TRY(dev_alloc(c, c->packed_index, mc));
+    TRY(dev_alloc(c, c->pack_a, mc));
+    TRY(dev_alloc(c, c->pack_vo, mc));
+    TRY(dev_alloc(c, c->pack_counts, 4));
+  }
+  if (geometry_capacity)
+    HIP_TRY(c, hipMemcpyAsync(c->pub_geometries.p, geometries, (size_t)geometry_capacity * 32,
+                              hipMemcpyHostToDevice, c->stream));
+  if (submesh_count)
+    HIP_TRY(c, hipMemcpyAsync(c->pub_submeshes.p, submeshes, (size_t)submesh_count * 16,
+                              hipMemcpyHostToDevice, c->stream));
+  if (material_capacity)
+    HIP_TRY(c, hipMemcpyAsync(c->pub_materials.p, materials, (size_t)material_capacity * 16,
+                              hipMemcpyHostToDevice, c->stream));
+  const uint64_t n = c->n_cand;
+  if (n) {
+    PackResolveArgs a{};
+    a.ident = c->ident.p;
+    a.geometries = c->pub_geometries.p;
+    a.submeshes = c->pub_submeshes.p;
+    a.materials = c->pub_materials.p;
+    a.cflags = c->cflags.p;
+    a.pack_a = c->pack_a.p;
+    a.pack_vo = c->pack_vo.p;
+    a.status = c->pack_status.p;
+    a.n = n;
+    a.geometry_capacity = geometry_capacity;
+    a.material_capacity = material_capacity;
+    hipLaunchKernelGGL(k_pack_resolve, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream, a);
+  }
+  hipLaunchKernelGGL(k_pack_index, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, c->pack_status.p,
+                     c->packed_index.p, n, c->pack_counts.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->pack_counts_host, c->pack_counts.p, 16, hipMemcpyDeviceToHost,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->published = true;
+  return VKRHIP_OK;
+}
+
 }  // extern "C"
+
+static int launch_pack(vkrhip_ctx *c) {
+  const uint64_t mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
+  if (!c->packed_rows.p) {
+    TRY(dev_alloc(c, c->packed_rows, mc * 3));
+    TRY(dev_alloc(c, c->packed_instances, mc * 5));
+  }
+  if (!c->n_cand) return VKRHIP_OK;
+  PackEmitArgs a{};
+  a.status = c->pack_status.p;
+  a.packed_index = c->packed_index.p;
+  a.pack_a = c->pack_a.p;
+  a.pack_vo = c->pack_vo.p;
+  a.cflags = c->cflags.p;
+  a.sphere = c->sphere.p;
+  a.ident = c->ident.p;
+  a.world = c->world.p;
+  a.node = c->node_identity ? nullptr : c->node.p;
+  a.rows = c->packed_rows.p;
+  a.instances = c->packed_instances.p;
+  a.n = c->n_cand;
+  hipLaunchKernelGGL(k_emit_packed, dim3((unsigned)ceil_div(c->n_cand, 32)), dim3(256), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+static int launch_encode(vkrhip_ctx *c) {
+  if (!c->visible_rows.p)
+    TRY(dev_alloc(c, c->visible_rows, (size_t)c->cfg.max_views * c->visible_stride * 2));
+  if (c->cfg.partition_capacity && !c->commands.p)
+    TRY(dev_alloc(c, c->commands, (size_t)c->cfg.max_views * 4u * c->cfg.partition_capacity * 5u));
+  if (!c->n_cand) return VKRHIP_OK;
+  EncodeArgs a{};
+  a.visible = c->visible.p;
+  a.states = c->states.p;
+  a.rows = c->packed_rows.p;
+  a.visible_rows = c->visible_rows.p;
+  a.commands = c->commands.p;
+  a.visible_stride = c->visible_stride;
+  a.views = c->views;
+  a.partition_capacity = c->cfg.partition_capacity;
+  // visible counts live on the device: cover what the packed rows can yield
+  const uint64_t slots = std::min<uint64_t>(c->pack_counts_host[0], c->visible_stride);
+  if (!slots) return VKRHIP_OK;
+  hipLaunchKernelGGL(k_encode_visible, dim3((unsigned)ceil_div(slots * 2, 256), c->views), dim3(256), 0,
+                     c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
 
 // ---------------------------------------------------------------------------
 // the frame
@@ -801,6 +942,7 @@ static int launch_compaction(vkrhip_ctx *c) {
     g.seg_first = c->seg_first.p;
     g.row_totals = c->row_totals.p;
     g.tkey = c->tkey.p;
+    g.remap = c->published ? c->packed_index.p : nullptr;
     g.states = c->states.p;
     g.visible = c->visible.p;
     g.keys = c->keys_a.p;
@@ -914,6 +1056,11 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     return fail(c, VKRHIP_ERR_STATE, "STAGE_TRANSPARENT needs STAGE_CULL in the same frame");
   if ((stages & VKRHIP_STAGE_WORLD_BOUNDS) && !(stages & VKRHIP_STAGE_CULL))
     return fail(c, VKRHIP_ERR_STATE, "STAGE_WORLD_BOUNDS needs STAGE_CULL in the same frame");
+  if ((stages & (VKRHIP_STAGE_PACK | VKRHIP_STAGE_ENCODE)) && !c->published)
+    return fail(c, VKRHIP_ERR_STATE, "STAGE_PACK / STAGE_ENCODE need vkrhip_set_publication");
+  if ((stages & VKRHIP_STAGE_ENCODE) &&
+      (stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_PACK)) != (VKRHIP_STAGE_CULL | VKRHIP_STAGE_PACK))
+    return fail(c, VKRHIP_ERR_STATE, "STAGE_ENCODE needs STAGE_CULL and STAGE_PACK in the same frame");
   if ((stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_CANDIDATES)) && c->node_identity &&
       c->n_cand > c->cfg.max_nodes)
     return fail(c, VKRHIP_ERR_STATE, "identity node mapping with more candidates than nodes");
@@ -941,6 +1088,8 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     if (cull) TRY(launch_compaction(c));
     if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c));
     if (stages & VKRHIP_STAGE_CANDIDATES) TRY(launch_candidates(c));
+    if (stages & VKRHIP_STAGE_PACK) TRY(launch_pack(c));
+    if (stages & VKRHIP_STAGE_ENCODE) TRY(launch_encode(c));
   }
   c->frame_ran = true;
   c->last_stages = stages;
@@ -980,6 +1129,12 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) {
   out->transparent_overflow = cnt[CNT_TRANSPARENT_TOTAL] - cnt[CNT_TRANSPARENT];
   out->nodes_updated = cnt[CNT_NODES_UPDATED];
   out->view_count = c->views;
+  if (c->published) {
+    out->packed_count = c->pack_counts_host[0];
+    out->unpublished_geometry_count = c->pack_counts_host[1];
+    out->unpublished_material_count = c->pack_counts_host[2];
+    out->invalid_submesh_count = c->pack_counts_host[3];
+  }
   for (uint32_t v = c->views; v < VKRHIP_MAX_VIEWS; ++v) {
     std::memset(&out->views[v], 0, sizeof(out->views[v]));
     out->near_plane_ties[v] = 0;
@@ -1002,6 +1157,10 @@ int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   out->gpu_candidates = c->cand_rows.p;
   out->world_bounds = reinterpret_cast<const float *>(c->world_bounds.p);
   out->device_counts = c->counters();
+  out->packed_rows = c->packed_rows.p;
+  out->packed_instances = c->packed_instances.p;
+  out->visible_rows = c->visible_rows.p;
+  out->commands = c->commands.p;
   return VKRHIP_OK;
 }
 
@@ -1063,6 +1222,34 @@ int vkrhip_read_candidates(vkrhip_ctx *c, uint64_t first, uint64_t count, void *
   if (!c->cand_rows.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_CANDIDATES has not run");
   TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_candidates"));
   return read_back(c, rows144, c->cand_rows.p + first * 9, count * 144);
+}
+
+int vkrhip_read_packed(vkrhip_ctx *c, uint64_t count, void *rows48, void *instances80) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if (!c->packed_rows.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_PACK has not run");
+  TRY(check_range(c, 0, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_packed"));
+  if (rows48) TRY(read_back(c, rows48, c->packed_rows.p, count * 48));
+  if (instances80) TRY(read_back(c, instances80, c->packed_instances.p, count * 80));
+  return VKRHIP_OK;
+}
+
+int vkrhip_read_visible_rows(vkrhip_ctx *c, uint32_t view, uint64_t count, void *rows32) {
+  if (!c || !rows32) return VKRHIP_ERR_ARG;
+  if (!c->visible_rows.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_ENCODE has not run");
+  if (view >= c->cfg.max_views) return fail(c, VKRHIP_ERR_ARG, "view %u out of range", view);
+  TRY(check_range(c, 0, count, c->visible_stride, "read_visible_rows"));
+  return read_back(c, rows32, c->visible_rows.p + (size_t)view * c->visible_stride * 2, count * 32);
+}
+
+int vkrhip_read_commands(vkrhip_ctx *c, uint32_t view, uint32_t bucket, uint64_t count,
+                         void *commands20) {
+  if (!c || !commands20) return VKRHIP_ERR_ARG;
+  if (!c->commands.p) return fail(c, VKRHIP_ERR_STATE, "no indirect commands (STAGE_ENCODE with a partition capacity)");
+  if (view >= c->cfg.max_views || bucket >= 4u) return fail(c, VKRHIP_ERR_ARG, "view/bucket out of range");
+  TRY(check_range(c, 0, count, c->cfg.partition_capacity, "read_commands"));
+  return read_back(c, commands20,
+                   c->commands.p + ((size_t)view * 4u + bucket) * c->cfg.partition_capacity * 5u,
+                   count * 20);
 }
 
 int vkrhip_read_world_bounds(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out4) {

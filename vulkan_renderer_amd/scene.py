@@ -32,6 +32,28 @@ DRAW_DT = np.dtype({
 INSTANCE_DT = np.dtype({
     "names": ["model", "object_id", "reserved"], "formats": ["16<f4", "<u4", "3<u4"],
     "offsets": [0, 64, 68], "itemsize": 80})                      # VkrInstanceDataGPU
+GPU_ROW_DT = np.dtype({  # VkrGpuCandidateDrawRow, lib/src/renderer/vkr_gpu_abi.h:70-80
+    "names": ["geometry_index", "material_index", "instance_index", "first_index", "index_count",
+              "vertex_offset", "state_bucket", "flags", "sphere"],
+    "formats": ["<u4", "<u4", "<u4", "<u4", "<u4", "<i4", "<u4", "<u4", "4<f4"],
+    "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32], "itemsize": 48})
+VISIBLE_ROW_DT = np.dtype({  # VkrGpuVisibleDrawRow, lib/src/renderer/vkr_gpu_abi.h:83-92
+    "names": ["geometry_index", "material_index", "instance_index", "first_index", "index_count",
+              "vertex_offset", "state_bucket", "flags"],
+    "formats": ["<u4", "<u4", "<u4", "<u4", "<u4", "<i4", "<u4", "<u4"],
+    "offsets": [0, 4, 8, 12, 16, 20, 24, 28], "itemsize": 32})
+COMMAND_DT = np.dtype({  # VkrVkIndirectCommand, deferred.slang:21-28
+    "names": ["index_count", "instance_count", "first_index", "vertex_offset", "first_instance"],
+    "formats": ["<u4", "<u4", "<u4", "<i4", "<u4"], "offsets": [0, 4, 8, 12, 16], "itemsize": 20})
+GEOMETRY_DT = np.dtype({  # vkrhip_geometry_entry
+    "names": ["generation", "resolvable", "first_index", "submesh_count", "submesh_offset"],
+    "formats": ["<u4"] * 5, "offsets": [0, 4, 8, 12, 16], "itemsize": 32})
+SUBMESH_DT = np.dtype({  # vkrhip_submesh_range
+    "names": ["first_index", "index_count", "vertex_offset"],
+    "formats": ["<u4", "<u4", "<i4"], "offsets": [0, 4, 8], "itemsize": 16})
+MATERIAL_DT = np.dtype({  # vkrhip_material_entry
+    "names": ["generation", "live", "slot_index"],
+    "formats": ["<u4"] * 3, "offsets": [0, 4, 8], "itemsize": 16})
 CANDIDATE_DT = np.dtype({
     "names": ["mesh", "geometry", "submesh_index", "material", "model", "object_id",
               "reserved", "sphere", "state_bucket", "flags"],
@@ -62,6 +84,10 @@ class FrameResult:
     transparent_overflow: int
     nodes_updated: int
     views: list
+    packed_count: int = 0
+    unpublished_geometry_count: int = 0
+    unpublished_material_count: int = 0
+    invalid_submesh_count: int = 0
 
 
 def _check(lib, ctx, rc: int) -> None:
@@ -185,6 +211,16 @@ class HipScene:
                                            N.ptr(view)))
         self.views = planes.shape[0]
 
+    def set_publication(self, geometries, submeshes, materials) -> None:
+        """Backend publication tables (structured arrays of GEOMETRY_DT, SUBMESH_DT,
+        MATERIAL_DT): entry k describes handle id k + 1. Enables STAGE_PACK /
+        STAGE_ENCODE; the visible lists hold packed row indices from then on."""
+        g = np.ascontiguousarray(geometries, dtype=GEOMETRY_DT)
+        sm = np.ascontiguousarray(submeshes, dtype=SUBMESH_DT)
+        m = np.ascontiguousarray(materials, dtype=MATERIAL_DT)
+        self._ok(self.lib.vkrhip_set_publication(self.ctx, N.ptr(g), g.shape[0], N.ptr(sm),
+                                                 sm.shape[0], N.ptr(m), m.shape[0]))
+
     # ---- the frame ------------------------------------------------------
     def frame(self, stages: int = N.STAGE_ALL) -> None:
         self._ok(self.lib.vkrhip_frame(self.ctx, stages))
@@ -211,7 +247,10 @@ class HipScene:
             transmission_gpu_candidate_count=info.transmission_gpu_candidate_count,
             transparent_draw_count=info.transparent_draw_count,
             transparent_overflow=info.transparent_overflow,
-            nodes_updated=info.nodes_updated, views=views)
+            nodes_updated=info.nodes_updated, views=views, packed_count=info.packed_count,
+            unpublished_geometry_count=info.unpublished_geometry_count,
+            unpublished_material_count=info.unpublished_material_count,
+            invalid_submesh_count=info.invalid_submesh_count)
 
     def device_outputs(self) -> N.DeviceOutputs:
         out = N.DeviceOutputs()
@@ -259,6 +298,24 @@ class HipScene:
     def read_candidates(self) -> np.ndarray:
         out = np.zeros(self.n_candidates, CANDIDATE_DT)
         self._ok(self.lib.vkrhip_read_candidates(self.ctx, 0, self.n_candidates, N.ptr(out)))
+        return out
+
+    def read_packed(self, count: int):
+        rows = np.zeros(count, GPU_ROW_DT)
+        inst = np.zeros(count, INSTANCE_DT)
+        self._ok(self.lib.vkrhip_read_packed(self.ctx, count, N.ptr(rows), N.ptr(inst)))
+        return rows, inst
+
+    def read_visible_rows(self, view: int, count: int) -> np.ndarray:
+        out = np.zeros(count, VISIBLE_ROW_DT)
+        if count:
+            self._ok(self.lib.vkrhip_read_visible_rows(self.ctx, view, count, N.ptr(out)))
+        return out
+
+    def read_commands(self, view: int, bucket: int, count: int) -> np.ndarray:
+        out = np.zeros(count, COMMAND_DT)
+        if count:
+            self._ok(self.lib.vkrhip_read_commands(self.ctx, view, bucket, count, N.ptr(out)))
         return out
 
     def read_world_bounds(self) -> np.ndarray:
