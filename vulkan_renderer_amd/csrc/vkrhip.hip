@@ -5,6 +5,7 @@
 #include "../../include/vkr_hip_scene.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -33,6 +34,7 @@ thread_local std::string g_create_error;
 struct EventPair {
   hipEvent_t start, stop;
   int timer;
+  int samples;  // what the pair adds to the timer's sample count (0: a further launch of a stage)
 };
 
 template <typename T>
@@ -228,6 +230,7 @@ struct StageTimer {
       }
     }
     ev.timer = timer;
+    ev.samples = 1;
     on = hipEventRecord(ev.start, c->stream) == hipSuccess;
     if (!on) c->free_events.push_back(ev);
   }
@@ -244,11 +247,43 @@ int drain_timers(vkrhip_ctx *c) {
     HIP_TRY(c, hipEventSynchronize(ev.stop));
     HIP_TRY(c, hipEventElapsedTime(&ms, ev.start, ev.stop));
     c->timer_ms[ev.timer] += ms;
-    c->timer_n[ev.timer] += 1;
+    c->timer_n[ev.timer] += (uint64_t)ev.samples;
     c->free_events.push_back(ev);
   }
   c->pending.clear();
   return VKRHIP_OK;
+}
+
+// Launch of one of the heavy kernels (transform, classify, fused). When its
+// timer is on, the launch carries its own event pair, which brackets the kernel
+// itself (dispatch start/end timestamps) rather than a stretch of the stream; a
+// stage of several launches (one per hierarchy level) accumulates into one
+// sample.
+template <typename K, typename A>
+void launch_timed(vkrhip_ctx *c, int timer, bool first_of_stage, K kernel, dim3 grid, dim3 block,
+                  size_t lds, const A &args) {
+  if (c->profiling & (1u << timer)) {
+    EventPair ev{};
+    bool have = false;
+    if (!c->free_events.empty()) {
+      ev = c->free_events.back();
+      c->free_events.pop_back();
+      have = true;
+    } else if (hipEventCreate(&ev.start) == hipSuccess) {
+      if (hipEventCreate(&ev.stop) == hipSuccess)
+        have = true;
+      else
+        (void)hipEventDestroy(ev.start);
+    }
+    if (have) {
+      ev.timer = timer;
+      ev.samples = first_of_stage ? 1 : 0;
+      hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, c->stream, ev.start, ev.stop, 0u, args);
+      c->pending.push_back(ev);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, c->stream, args);
 }
 
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
@@ -783,16 +818,19 @@ static CullArgs cull_args(vkrhip_ctx *c) {
 }
 
 static int launch_transform(vkrhip_ctx *c) {
-  StageTimer timer(c, VKRHIP_TIMER_TRANSFORM);
+  bool first = true;
   const uint32_t levels = c->level_offsets.empty() ? 0u : (uint32_t)c->level_offsets.size() - 1u;
   for (uint32_t l = 0; l < levels; ++l) {
     const TransformArgs a = transform_args(c, l);
     if (a.end == a.begin) continue;
     const unsigned grid = (unsigned)ceil_div(a.end - a.begin, TF_TILE);
     if (l == 0 || !c->parent.p)
-      hipLaunchKernelGGL(k_propagate_level<false>, dim3(grid), dim3(TF_BLOCK), 0, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_level<false>, dim3(grid),
+                   dim3(TF_BLOCK), 0, a);
     else
-      hipLaunchKernelGGL(k_propagate_level<true>, dim3(grid), dim3(TF_BLOCK), 0, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_level<true>, dim3(grid),
+                   dim3(TF_BLOCK), 0, a);
+    first = false;
   }
   c->force_flags = 0;
   HIP_TRY(c, hipGetLastError());
@@ -830,19 +868,19 @@ static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *roun
 
 template <bool HAS_PARENT>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
-                                 bool bounds_out) {
+                                 bool bounds_out, bool first) {
   const dim3 g(grid), b(FUSED_BLOCK);
   const size_t lds = cull_shared_bytes(a.c.views);
   if (ties) {
     if (bounds_out)
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, true>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true>, g, b, lds, a);
     else
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, true, false>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false>, g, b, lds, a);
   } else {
     if (bounds_out)
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, true>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true>, g, b, lds, a);
     else
-      hipLaunchKernelGGL((k_propagate_classify<HAS_PARENT, false, false>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false>, g, b, lds, a);
   }
 }
 
@@ -855,7 +893,7 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     segments += fused_level_grid(c, l, &rounds);
   }
   TRY(ensure_segments(c, segments));
-  StageTimer timer(c, VKRHIP_TIMER_FUSED);
+  bool first = true;
   const bool ties = c->cfg.tie_epsilon > 0.f;
   uint64_t seg_base = 0;
   for (uint32_t l = 0; l < levels; ++l) {
@@ -866,9 +904,10 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.c = cull_args(c);
     a.seg_base = (uint32_t)seg_base;
     if (l == 0 || !c->parent.p)
-      launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out);
+      launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
     else
-      launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out);
+      launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
+    first = false;
     seg_base += grid;
   }
   c->segments = segments;
@@ -884,14 +923,14 @@ static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned g
   const size_t lds = cull_shared_bytes(a.views);
   if (ties) {
     if (bounds_out)
-      hipLaunchKernelGGL((k_classify<IDENTITY, true, true>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, true>, g, b, lds, a);
     else
-      hipLaunchKernelGGL((k_classify<IDENTITY, true, false>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, false>, g, b, lds, a);
   } else {
     if (bounds_out)
-      hipLaunchKernelGGL((k_classify<IDENTITY, false, true>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, false, true>, g, b, lds, a);
     else
-      hipLaunchKernelGGL((k_classify<IDENTITY, false, false>), g, b, lds, c->stream, a);
+      launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, false, false>, g, b, lds, a);
   }
 }
 
@@ -899,7 +938,6 @@ static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
   c->segments = ceil_div(c->n_cand, CULL_TILE);
   if (!c->n_cand) return VKRHIP_OK;
   TRY(ensure_segments(c, c->segments));
-  StageTimer timer(c, VKRHIP_TIMER_CLASSIFY);
   const CullArgs a = cull_args(c);
   const bool ties = c->cfg.tie_epsilon > 0.f;
   if (c->node_identity)
