@@ -49,8 +49,11 @@ WORKLOADS = {
 #   classify : world 64 + sphere 16 + flags 4 in; visibility byte 1 out, plus 4 per
 #              surviving (instance, view) (the staged survivor index)
 #   fused    : both, minus the re-read of world (it is classified in registers)
-def kernel_bytes(name: str, n: int, depth: int, survivors: int) -> float:
+def kernel_bytes(name: str, n: int, depth: int, survivors: int, dirty_local: bool = False) -> float:
     transform = 64 + 64 + 2 + (4 if depth > 1 else 0)
+    if dirty_local:  # TRS 48 in instead of the cached local, rebuilt local 64 out
+        transform += 48
+
     classify_in, classify_out = 64 + 16 + 4, 1
     if name == "transform":
         return n * transform
@@ -110,6 +113,9 @@ def main() -> int:
     ap.add_argument("--depth", type=int, default=-1, help="override hierarchy depth")
     ap.add_argument("--cascades", type=int, default=-1, help="override shadow cascade count")
     ap.add_argument("--probes", type=int, default=-1, help="override extra probe views")
+    ap.add_argument("--dirty", default="world", choices=["world", "local"],
+                    help="what moves every frame: world = cached local matrices are re-propagated "
+                         "(default); local = every node's TRS changed, locals are rebuilt too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -165,8 +171,10 @@ def main() -> int:
     hs.sync()
     exchange = ShardExchange(hs, world, rank, views) if world > 1 else None
 
+    dirty_bits = N.DIRTY_LOCAL if args.dirty == "local" else N.DIRTY_WORLD
+
     def step():
-        hs.mark_all(N.DIRTY_WORLD)   # every node moved this frame
+        hs.mark_all(dirty_bits)      # every node moved this frame
         hs.frame(N.STAGE_ALL)
         if exchange is not None:
             exchange.run()
@@ -216,9 +224,10 @@ def main() -> int:
     dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
     launches = 1 if dominant == "classify" else len(sc.level_offsets) - 1
     survivors = sum(st.visible_count for st in info.views) + info.transparent_draw_count
-    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors)
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors, args.dirty == "local")
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-    overridden = bool(args.instances) or any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes"))
+    overridden = (bool(args.instances) or args.dirty != "world" or
+                  any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes")))
     traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant])
     roofline = {
         "bound": "hbm", "kernel": KERNEL_NAMES[dominant],
@@ -242,6 +251,8 @@ def main() -> int:
             "hierarchy_depth": len(sc.level_offsets) - 1,
             "visible_camera": info.views[0].visible_count,
             "transparent_draws": info.transparent_draw_count,
+            "moved_per_frame": "every node: " + ("TRS (locals rebuilt)" if args.dirty == "local"
+                                                 else "world matrices re-propagated from cached locals"),
             "exchange": "allgather visible lists + draw-key merge" if world > 1 else "none",
         },
         "roofline": roofline,

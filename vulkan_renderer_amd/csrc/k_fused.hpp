@@ -66,7 +66,10 @@ __device__ __forceinline__ void wave_min_max(uint32_t p, uint32_t &mn, uint32_t 
 // 32-bit offsets into the block's 1024-node tile; [lo, hi) is the part of the
 // tile that belongs to the level.
 struct FusedHead {
-  uint32_t f[4];  // node flag bytes; after fused_resolve_head: pass-1 state, 0 outside the level
+  uint32_t raw[4];  // node flag bytes as loaded
+  uint32_t fp;      // after fused_resolve_head: the four pass-1 flag bytes packed (byte r =
+                    // sub-round r), 0 outside the level
+  __device__ __forceinline__ uint32_t f(int r) const { return (fp >> (8 * r)) & 0xffu; }
   uint32_t p;     // parent of node (round base + thread)
   float4 ls;      // local sphere of candidate (round base + thread)
   uint32_t cf;
@@ -92,7 +95,7 @@ __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t ti
   h.cf = a.c.cflags[ci];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    h.f[r] = a.t.flags[tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi)];
+    h.raw[r] = a.t.flags[tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi)];
 }
 
 // Waits for the head's loads. Applies the bulk dirty bits and pass 1's clearing
@@ -106,16 +109,16 @@ __device__ __forceinline__ void fused_resolve_head(const FusedArgs &a, uint64_t 
   h.p |= ~m;  // NO_PARENT outside the level
   if (tile_base + rel >= a.c.n) m = 0u;
   h.cf = (h.cf & m) | (0xf0u & ~m);  // invalid bucket: fails every gate
+  h.fp = 0u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint32_t mr = in_range_mask(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi);
-    h.f[r] = ((h.f[r] | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & mr;
+    h.fp |= ((((h.raw[r] | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & mr) & 0xffu) << (8 * r);
   }
 }
 
 struct FusedBody {
-  float4 m[4];          // local column (have_local bit r) or stored world column, per sub-round
-  uint32_t have_local;  // bit r
+  float4 m[4];  // per sub-round: the local column when the node is dirty, else the stored world column
 };
 
 // Needs a resolved head. The node's own flags pick the matrix to fetch: dirty ->
@@ -127,29 +130,32 @@ __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t ti
                                                  FusedHead &h, FusedBody &b) {
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
-  b.have_local = 0u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t node = tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi);
-    const bool hl = (h.f[r] & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
+    const uint32_t f = h.f(r);
+    const bool hl = (f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
     const float4 *src = hl ? a.t.local : a.t.world;
-    b.m[r] = src[node * 4u + col];
-    b.have_local |= hl ? (1u << r) : 0u;
+    // a local that is about to be rebuilt from TRS is not fetched: those lanes
+    // all read one fixed element instead (a single cached request), which keeps
+    // the load unconditional
+    const bool rebuilt = a.t.pos != nullptr && (f & F_DIRTY_LOCAL) != 0;
+    b.m[r] = src[rebuilt ? a.t.begin * 4u : node * 4u + col];
   }
   // pass 1, vkr_scene_system.c:598-602: a changed TRS rebuilds the local matrix
   if (a.t.pos != nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (h.f[r] & F_DIRTY_LOCAL) {
+      if (h.f(r) & F_DIRTY_LOCAL) {
         const uint64_t node = tile_base + rbase + (uint32_t)r * 64u + (t >> 2);
         b.m[r] = local_col_from_trs(a.t.pos[node], a.t.quat[node], a.t.scale[node], col);
         a.t.local[node * 4u + col] = b.m[r];
       }
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)  // DIRTY_LOCAL becomes DIRTY_WORLD
-    h.f[r] = (h.f[r] | ((h.f[r] & F_DIRTY_LOCAL) << 1)) & ~(uint32_t)F_DIRTY_LOCAL;
+  // DIRTY_LOCAL becomes DIRTY_WORLD (all four bytes at once); from here on a set
+  // DIRTY_WORLD bit also says that b.m holds the local column
+  h.fp = (h.fp | ((h.fp & 0x01010101u * F_DIRTY_LOCAL) << 1)) & ~(0x01010101u * F_DIRTY_LOCAL);
 }
 
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT>
@@ -251,8 +257,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       if (HAS_PARENT && par[r] != NO_PARENT) {
         const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.t.flags[par[r]];
         if (pf & F_WORLD_UPDATED) {
-          hd.f[r] |= F_DIRTY_WORLD;
-          if (!(cur.have_local & (1u << r))) cur.m[r] = a.t.local[node * 4u + col];  // parent moved
+          if (!(hd.f(r) & F_DIRTY_WORLD)) cur.m[r] = a.t.local[node * 4u + col];  // parent moved
+          hd.fp |= (uint32_t)F_DIRTY_WORLD << (8 * r);
         }
       }
     }
@@ -263,7 +269,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       const bool valid = rbase + slot >= lo && rbase + slot < hi;
       float4 wcol = cur.m[r];
       bool did_update = false;
-      if (hd.f[r] & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
+      uint32_t fr = hd.f(r);
+      if (fr & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
         if (HAS_PARENT && par[r] != NO_PARENT) {
           float4 a0, a1, a2, a3;
           if (window) {
@@ -282,10 +289,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
           wcol = mat4_mul_col(a0, a1, a2, a3, cur.m[r]);
         }
         a.t.world[node * 4u + col] = wcol;
-        hd.f[r] = (hd.f[r] & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
+        fr = (fr & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
         did_update = true;
       }
-      if (valid && col == 0) a.t.flags[node] = (uint8_t)hd.f[r];
+      if (valid && col == 0) a.t.flags[node] = (uint8_t)fr;
       s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
       updated_here += (did_update && col == 0) ? 1u : 0u;  // per lane; summed when the block ends
     }
