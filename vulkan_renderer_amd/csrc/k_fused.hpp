@@ -14,18 +14,22 @@
 // round r+2 are requested before round r is consumed, so a block always has
 // more than a round's worth of HBM requests in flight while it computes.
 //
-// Thread mapping inside a round:
+// Inside a round every wave works on its own 64 consecutive nodes and never
+// waits for another wave:
 //   transform phase  4 lanes per node, lane j owns column j, four sub-rounds of
-//                    64 nodes: every wave load/store covers 1 KiB of consecutive
-//                    bytes;
-//   hand-over        the world columns go to LDS with an 80-byte node stride
-//                    (conflict-free 16-byte reads);
+//                    16 nodes: every wave load/store covers 1 KiB of consecutive
+//                    bytes. Below the root level the four lanes of a node fetch
+//                    one column each of the parent's world matrix (siblings are
+//                    contiguous in the BFS node order, so the 16 nodes of a
+//                    sub-round share a couple of parents and the requests merge)
+//                    and trade columns with quad DPP moves; the parent index
+//                    comes from the lane that loaded it by a wave shuffle;
+//   hand-over        the world columns go to the wave's stretch of LDS with an
+//                    80-byte node stride (conflict-free 16-byte reads);
 //   cull phase       one thread per node reads its four columns back and runs
 //                    classify_candidate().
-// Parent world matrices of a round are staged in LDS when the round's parents
-// form a window of at most FUSED_WINDOW nodes (siblings are contiguous and
-// parents ascend in the BFS node order, so 256 nodes of fan-out >= 2 qualify);
-// otherwise lanes read their parent through the cache hierarchy.
+// The only block-wide barriers are the one after the LDS tables are cleared and
+// those of the end-of-segment packing.
 #pragma once
 #include "k_cull.hpp"
 #include "k_transform.hpp"
@@ -34,7 +38,7 @@ namespace vkr {
 
 constexpr int FUSED_BLOCK = 256;
 constexpr int FUSED_ROUNDS = CULL_TILE / FUSED_BLOCK;  // 4
-constexpr int FUSED_WINDOW = 128;                      // LDS-staged parent window (nodes)
+constexpr uint32_t F_HAS_PARENT = 0x80u;  // marker in the prefetched parent flag byte (not a scene flag)
 
 struct FusedArgs {
   TransformArgs t;
@@ -43,17 +47,21 @@ struct FusedArgs {
   uint32_t seg_base;  // cull segment of block 0 of this launch (segments follow launch order)
 };
 
-// min and max of `p` over the lanes of the wave that hold a parent index
-__device__ __forceinline__ void wave_min_max(uint32_t p, uint32_t &mn, uint32_t &mx) {
-  mn = p;  // NO_PARENT = 0xffffffff never wins the min
-  mx = p == NO_PARENT ? 0u : p;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t on = (uint32_t)__shfl_xor((int)mn, d, 64);
-    const uint32_t ox = (uint32_t)__shfl_xor((int)mx, d, 64);
-    mn = on < mn ? on : mn;
-    mx = ox > mx ? ox : mx;
-  }
+// Value of lane (quad base + K) for every lane of the quad (quad_perm DPP move).
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ float4 quad_bcast4(float4 v) {
+  return make_float4(quad_bcast<K>(v.x), quad_bcast<K>(v.y), quad_bcast<K>(v.z), quad_bcast<K>(v.w));
+}
+
+// Node a lane works on in sub-round r of a round, relative to the round's first
+// node: the wave's 64 nodes in four groups of 16, four lanes per node.
+__device__ __forceinline__ uint32_t sub_slot(int r) {
+  return (threadIdx.x & ~63u) + (uint32_t)r * 16u + ((threadIdx.x & 63u) >> 2);
 }
 
 // What one thread loads for one round, in two dependent steps: the head (flags,
@@ -66,13 +74,13 @@ __device__ __forceinline__ void wave_min_max(uint32_t p, uint32_t &mn, uint32_t 
 // 32-bit offsets into the block's 1024-node tile; [lo, hi) is the part of the
 // tile that belongs to the level.
 struct FusedHead {
-  uint32_t raw[4];  // node flag bytes as loaded
+  uint32_t raw[4];  // node flag bytes as loaded (sub-round mapping)
   uint32_t fp;      // after fused_resolve_head: the four pass-1 flag bytes packed (byte r =
                     // sub-round r), 0 outside the level
-  __device__ __forceinline__ uint32_t f(int r) const { return (fp >> (8 * r)) & 0xffu; }
-  uint32_t p;     // parent of node (round base + thread)
-  float4 ls;      // local sphere of candidate (round base + thread)
+  uint32_t p;       // parent of node (round base + thread)
+  float4 ls;        // local sphere of candidate (round base + thread)
   uint32_t cf;
+  __device__ __forceinline__ uint32_t f(int r) const { return (fp >> (8 * r)) & 0xffu; }
 };
 
 __device__ __forceinline__ uint32_t clamp_rel(uint32_t rel, uint32_t lo, uint32_t hi) {
@@ -95,7 +103,7 @@ __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t ti
   h.cf = a.c.cflags[ci];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    h.raw[r] = a.t.flags[tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi)];
+    h.raw[r] = a.t.flags[tile_base + clamp_rel(rbase + sub_slot(r), lo, hi)];
 }
 
 // Waits for the head's loads. Applies the bulk dirty bits and pass 1's clearing
@@ -112,7 +120,7 @@ __device__ __forceinline__ void fused_resolve_head(const FusedArgs &a, uint64_t 
   h.fp = 0u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t mr = in_range_mask(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi);
+    const uint32_t mr = in_range_mask(rbase + sub_slot(r), lo, hi);
     h.fp |= ((((h.raw[r] | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & mr) & 0xffu) << (8 * r);
   }
 }
@@ -123,8 +131,8 @@ struct FusedBody {
 
 // Needs a resolved head. The node's own flags pick the matrix to fetch: dirty ->
 // the local column; clean -> the stored world column (the cull phase needs it
-// unless the parent turns out to have moved, which is handled when the parents
-// are known).
+// unless the parent turns out to have moved, which is handled when the round is
+// computed).
 __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h, FusedBody &b) {
@@ -132,7 +140,7 @@ __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t ti
   const uint32_t col = t & 3u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint64_t node = tile_base + clamp_rel(rbase + (uint32_t)r * 64u + (t >> 2), lo, hi);
+    const uint64_t node = tile_base + clamp_rel(rbase + sub_slot(r), lo, hi);
     const uint32_t f = h.f(r);
     const bool hl = (f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
     const float4 *src = hl ? a.t.local : a.t.world;
@@ -147,7 +155,7 @@ __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t ti
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (h.f(r) & F_DIRTY_LOCAL) {
-        const uint64_t node = tile_base + rbase + (uint32_t)r * 64u + (t >> 2);
+        const uint64_t node = tile_base + rbase + sub_slot(r);
         b.m[r] = local_col_from_trs(a.t.pos[node], a.t.quat[node], a.t.scale[node], col);
         a.t.local[node * 4u + col] = b.m[r];
       }
@@ -160,12 +168,10 @@ __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t ti
 
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT>
 __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a) {
-  __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];
-  __shared__ float4 s_pworld[HAS_PARENT ? FUSED_WINDOW * 4 : 1];
-  __shared__ uint8_t s_pflags[HAS_PARENT ? FUSED_WINDOW : 1];
-  __shared__ uint32_t s_par[HAS_PARENT ? FUSED_BLOCK : 1];
-  __shared__ uint32_t s_wmin[4], s_wmax[4], s_updated;
+  __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
+  __shared__ uint32_t s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
+  static_assert((F_DIRTY_LOCAL | F_DIRTY_WORLD | F_WORLD_UPDATED) < F_HAS_PARENT, "marker bit is free");
 
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
     fused_issue_body(a, tile_base, lo, hi, 0u, head_next, body_next);
   }
   uint32_t updated_here = 0;
+  __syncthreads();  // LDS tables cleared
 
 #pragma unroll
   for (int round = 0; round < FUSED_ROUNDS; ++round) {
@@ -220,83 +227,57 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, rbase + 2 * FUSED_BLOCK, head_after);
     if (!active(round)) continue;
 
-    // ---- parent window -------------------------------------------------------
-    bool window = false;
-    uint32_t pmin = 0;
-    if (HAS_PARENT) {
-      s_par[t] = hd.p;
-      uint32_t wmn, wmx;
-      wave_min_max(hd.p, wmn, wmx);
-      if ((t & 63u) == 0) {
-        s_wmin[t >> 6] = wmn;
-        s_wmax[t >> 6] = wmx;
-      }
-      __syncthreads();  // also: the previous round's readers of s_pworld are done
-      pmin = min(min(s_wmin[0], s_wmin[1]), min(s_wmin[2], s_wmin[3]));
-      const uint32_t pmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-      window = pmin != NO_PARENT && (pmax - pmin) < (uint32_t)FUSED_WINDOW;
-      if (window) {
-        const uint32_t span = pmax - pmin + 1u;
-        const float4 *src = a.t.world + (uint64_t)pmin * 4u;
-        for (uint32_t k = t; k < span * 4u; k += FUSED_BLOCK) s_pworld[k] = src[k];
-        for (uint32_t k = t; k < span; k += FUSED_BLOCK)
-          s_pflags[k] = a.t.flags[(uint64_t)pmin + k];
-      }
-    }
-    __syncthreads();  // window staged; accumulators cleared; s_mat free again
-
     // ---- transform phase -------------------------------------------------------
-    uint32_t par[4];
+    // Parents were finished by the previous level's launch. The four lanes of a
+    // node fetch one column each of the parent's world matrix; the parent index
+    // sits in the lane that loaded it for the cull mapping. Siblings share their
+    // parent, so the requests of a sub-round merge into a few cache lines.
+    float4 pc[HAS_PARENT ? 4 : 1];
+    uint32_t pfp = 0u;  // per sub-round byte: the parent's flags | F_HAS_PARENT, 0 for a root
+    if (HAS_PARENT) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
-      const uint64_t node = base + slot;
-      par[r] = NO_PARENT;
-      if (HAS_PARENT) par[r] = s_par[slot];
-      // deferred dirty propagation, vkr_scene_system.c:1310-1316
-      if (HAS_PARENT && par[r] != NO_PARENT) {
-        const uint8_t pf = window ? s_pflags[par[r] - pmin] : a.t.flags[par[r]];
-        if (pf & F_WORLD_UPDATED) {
-          if (!(hd.f(r) & F_DIRTY_WORLD)) cur.m[r] = a.t.local[node * 4u + col];  // parent moved
-          hd.fp |= (uint32_t)F_DIRTY_WORLD << (8 * r);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t par = (uint32_t)__shfl((int)hd.p, r * 16 + (int)((t & 63u) >> 2), 64);
+        const uint32_t pm = par != NO_PARENT ? 0xffffffffu : 0u;
+        const uint64_t pidx = par & pm;  // roots read node 0 and drop the result
+        pc[r] = a.t.world[pidx * 4u + col];
+        const uint32_t pflag = a.t.flags[pidx];
+        pfp |= (((pflag & 0x7fu) | F_HAS_PARENT) & pm & 0xffu) << (8 * r);
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const uint32_t slot = (uint32_t)r * 64u + (t >> 2);
+      const uint32_t slot = sub_slot(r);
       const uint64_t node = base + slot;
       const bool valid = rbase + slot >= lo && rbase + slot < hi;
-      float4 wcol = cur.m[r];
-      bool did_update = false;
       uint32_t fr = hd.f(r);
-      if (fr & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
-        if (HAS_PARENT && par[r] != NO_PARENT) {
-          float4 a0, a1, a2, a3;
-          if (window) {
-            const float4 *pw = s_pworld + (par[r] - pmin) * 4u;
-            a0 = pw[0];
-            a1 = pw[1];
-            a2 = pw[2];
-            a3 = pw[3];
-          } else {
-            const float4 *pw = a.t.world + (uint64_t)par[r] * 4u;
-            a0 = pw[0];
-            a1 = pw[1];
-            a2 = pw[2];
-            a3 = pw[3];
-          }
-          wcol = mat4_mul_col(a0, a1, a2, a3, cur.m[r]);
-        }
-        a.t.world[node * 4u + col] = wcol;
-        fr = (fr & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
-        did_update = true;
+      float4 lcol = cur.m[r];
+      const uint32_t pf = HAS_PARENT ? (pfp >> (8 * r)) & 0xffu : 0u;
+      // deferred dirty propagation, vkr_scene_system.c:1310-1316
+      if (HAS_PARENT && valid && (pf & F_WORLD_UPDATED) && !(fr & F_DIRTY_WORLD)) {
+        lcol = a.t.local[node * 4u + col];  // the parent moved: this node moves too
+        fr |= F_DIRTY_WORLD;
       }
+      float4 wcol = lcol;
+      bool did_update = false;
+      if (fr & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
+        did_update = true;
+        fr = (fr & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
+      }
+      if (HAS_PARENT) {
+        // all four lanes of the node take part in the column exchange
+        const float4 a0 = quad_bcast4<0>(pc[r]);
+        const float4 a1 = quad_bcast4<1>(pc[r]);
+        const float4 a2 = quad_bcast4<2>(pc[r]);
+        const float4 a3 = quad_bcast4<3>(pc[r]);
+        if (did_update && (pf & F_HAS_PARENT)) wcol = mat4_mul_col(a0, a1, a2, a3, lcol);
+      }
+      if (did_update) a.t.world[node * 4u + col] = wcol;
       if (valid && col == 0) a.t.flags[node] = (uint8_t)fr;
       s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
       updated_here += (did_update && col == 0) ? 1u : 0u;  // per lane; summed when the block ends
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();  // the wave's own columns: LDS keeps a wave's accesses in order
 
     // ---- cull phase ------------------------------------------------------------
     Mat4 m;
@@ -307,6 +288,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       m.c[2] = p[2];
       m.c[3] = p[3];
     }
+    __builtin_amdgcn_wave_barrier();  // read before the next round overwrites the slots
     const bool cvalid = rbase + t >= lo && rbase + t < hi && base + t < a.c.n;
     packed |= classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, m,
                                                    hd.ls, hd.cf)
