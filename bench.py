@@ -118,6 +118,8 @@ def main() -> int:
                          "(default); local = every node's TRS changed, locals are rebuilt too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--exchange", action="store_true",
+                    help="run the multi-GPU exchange step even with one rank (to time its launches)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
 
@@ -169,7 +171,7 @@ def main() -> int:
     hs.set_views(planes, required, vs.view)
     hs.frame(N.STAGE_TRANSFORM)  # materialise local matrices from TRS once (not timed)
     hs.sync()
-    exchange = ShardExchange(hs, world, rank, views) if world > 1 else None
+    exchange = ShardExchange(hs, world, rank, views) if (world > 1 or args.exchange) else None
 
     dirty_bits = N.DIRTY_LOCAL if args.dirty == "local" else N.DIRTY_WORLD
 
@@ -189,6 +191,8 @@ def main() -> int:
     hs.set_profiling(True)
     for _ in range(max(args.warmup, 1)):
         step()
+        if exchange is not None:
+            exchange.finish()        # sizes the exchange blocks (same decision on every rank)
     fence()
     warm = hs.timers(reset=True)
     dominant = max(("transform", "classify", "fused"), key=lambda k: warm[k][0])
@@ -215,6 +219,12 @@ def main() -> int:
         elapsed = float(t.item())
     timers = hs.timers(reset=True)
     info = hs.frame_info()
+    if exchange is not None:
+        regrown = exchange.regrown
+        exchange.finish()
+        if exchange.regrown != regrown:
+            print("bench.py: the exchange blocks overflowed inside the timed region", file=sys.stderr)
+            return 3
 
     ms_per_step = elapsed * 1e3 / args.steps
     total_instances = n * world
@@ -253,7 +263,8 @@ def main() -> int:
             "transparent_draws": info.transparent_draw_count,
             "moved_per_frame": "every node: " + ("TRS (locals rebuilt)" if args.dirty == "local"
                                                  else "world matrices re-propagated from cached locals"),
-            "exchange": "allgather visible lists + draw-key merge" if world > 1 else "none",
+            "exchange": ("one all-gather of packed blocks (visible lists + draw-key runs), "
+                         "device-planned merge") if exchange is not None else "none",
         },
         "roofline": roofline,
         "stage_us_warmup": stage_us,

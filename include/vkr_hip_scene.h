@@ -294,6 +294,35 @@ int vkrhip_merge_runs(vkrhip_ctx *ctx, uint32_t g, const uint64_t *const *runs_k
 int vkrhip_concat_ranges(vkrhip_ctx *ctx, const uint32_t *src_dev, uint32_t *dst_dev,
                          const uint64_t *desc, uint32_t n_desc);
 
+/* ---- multi-GPU exchange planned on the device (no reference counterpart) ------
+ * The per-frame exchange of one rank with the others without a host round trip:
+ *   vkrhip_exchange_pack   -> this rank's block in `block_dev`
+ *   (all-gather of the blocks with the caller's collective library, e.g. RCCL)
+ *   vkrhip_exchange_merge  -> merged visible lists, merged draw keys, result words
+ * All launches go to the context's stream and return at once.
+ *
+ * Block, in 32-bit words (vkrhip_exchange_block_words gives the total, a
+ * multiple of 4): execution_ranges[view][bucket] = {offset, count} for every
+ * view; {draw count, visible total, views, 0}; padding to a multiple of 4;
+ * vis_cap (rounded up to 4) visible candidate indices, the views' lists back to
+ * back; key_cap 64-bit draw keys in descending order. Lists longer than the
+ * capacities are cut; the header keeps the true counts and the merge flags it.
+ *
+ * Result, in 64-bit words (vkrhip_exchange_result_words): [0] flags (0 = merged
+ * outputs complete; 1 = some rank's visible lists exceeded vis_cap, 2 = some
+ * rank's keys exceeded key_cap, 4 = a block was packed for another view count),
+ * [1] largest visible total of a rank, [2] largest draw count of a rank, [3]
+ * merged visible total, [4] merged draw count, [5..7] zero, [8..8+views] start of
+ * every view in the merged list (+ the total), then views*4 {offset inside the
+ * view, count} pairs. merged_visible_dev holds world*vis_cap words and
+ * merged_keys_dev world*key_cap keys. */
+uint64_t vkrhip_exchange_block_words(uint32_t views, uint32_t vis_cap, uint32_t key_cap);
+uint64_t vkrhip_exchange_result_words(uint32_t views);
+int vkrhip_exchange_pack(vkrhip_ctx *ctx, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap);
+int vkrhip_exchange_merge(vkrhip_ctx *ctx, const uint32_t *gathered_dev, uint32_t world,
+                          uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
+                          uint64_t *merged_keys_dev, uint64_t *result_dev);
+
 /* ---- host-side mirrors of reference leaf functions (exact op order) -------- */
 /* vkr_frustum_from_matrix, lib/src/math/vkr_frustum.c:44-66 */
 void vkrhip_frustum_from_matrix(const float *view_projection, float *planes24);

@@ -97,3 +97,78 @@ def compare_frame(hs, ref, sc, check_transform=True, partition_capacity=0):
 
 def hs_index_base(hs):
     return getattr(hs, "_index_base", 0)
+
+
+# ---- the multi-rank exchange restated in numpy (checker for the exchange kernels,
+# and the stand-in source that lets the exchange run over gloo on CPU) ----------
+def numpy_exchange_pack(states, visible, keys, views, vis_cap, key_cap):
+    """One rank's exchange block as include/vkr_hip_scene.h lays it out."""
+    from vulkan_renderer_amd.parallel import exchange_block_words, exchange_header_words
+    vis_cap4, header = (vis_cap + 3) & ~3, exchange_header_words(views)
+    block = np.zeros(exchange_block_words(views, vis_cap, key_cap), np.uint32)
+    pos = 0
+    for v in range(views):
+        block[v * 8: v * 8 + 8] = np.asarray(states[v]["execution_ranges"], np.uint32).reshape(-1)
+        cnt = int(states[v]["visible_count"])
+        room = max(0, min(cnt, vis_cap - pos))
+        block[header + pos: header + pos + room] = visible[v][:room]
+        pos += cnt
+    block[views * 8: views * 8 + 4] = (len(keys), pos, views, 0)
+    kept = min(len(keys), key_cap)
+    key_words = block[header + vis_cap4: header + vis_cap4 + 2 * key_cap].view(np.uint64)
+    key_words[:kept] = np.asarray(keys[:kept], np.uint64)
+    return block
+
+
+def numpy_exchange_merge(oracle, gathered, world, views, vis_cap, key_cap):
+    """(flags, max_rank_visible, max_rank_keys, view_offsets, merged_ranges,
+    merged visible list, merged keys) from the gathered blocks."""
+    from vulkan_renderer_amd.parallel import (apply_descriptors, exchange_block_words,
+                                              exchange_header_words, plan_visible_merge)
+    words, header = exchange_block_words(views, vis_cap, key_cap), exchange_header_words(views)
+    vis_cap4 = (vis_cap + 3) & ~3
+    blocks = np.asarray(gathered, np.uint32).reshape(world, words)
+    ranges = blocks[:, : views * 8].reshape(world, views, 4, 2).astype(np.uint64)
+    draws = blocks[:, views * 8].astype(np.uint64)
+    rank_visible = ranges[..., 1].sum(axis=(1, 2))
+    flags = (1 if (rank_visible > vis_cap).any() else 0) | (2 if (draws > key_cap).any() else 0)
+    desc, merged_ranges, view_offsets, _ = plan_visible_merge(ranges)
+    lists = np.ascontiguousarray(blocks[:, header: header + vis_cap4])
+    merged = None
+    runs = None
+    if not flags:
+        merged = apply_descriptors(lists, vis_cap4, desc, world, int(view_offsets[-1]))
+        runs = [blocks[r, header + vis_cap4: header + vis_cap4 + 2 * key_cap].view(np.uint64)[: int(draws[r])]
+                for r in range(world)]
+        runs = oracle.merge_runs_desc(runs)
+    return (flags, int(rank_visible.max()), int(draws.max()), view_offsets, merged_ranges, merged, runs)
+
+
+class OracleShardSource:
+    """One rank's frame results from the CPU oracle, in the shape ShardExchange
+    asks for: pack() and merge() on CPU tensors."""
+
+    def __init__(self, oracle, frame, views):
+        import torch
+        self.oracle, self.frame, self.views = oracle, frame, views
+        self.device = torch.device("cpu")
+
+    def pack(self, block, vis_cap, key_cap):
+        f = self.frame
+        packed = numpy_exchange_pack(f["states"], f["visible"], f["payload"]["sort_keys"], self.views,
+                                     vis_cap, key_cap)
+        block.numpy().view(np.uint32)[:] = packed
+
+    def merge(self, gathered, world, vis_cap, key_cap, vis_merged, key_merged, result):
+        flags, max_vis, max_keys, view_offsets, merged_ranges, merged, keys = numpy_exchange_merge(
+            self.oracle, gathered.numpy().view(np.uint32), world, self.views, vis_cap, key_cap)
+        res = result.numpy().view(np.uint64)
+        res[:] = 0
+        res[0], res[1], res[2] = flags, max_vis, max_keys
+        res[3] = int(view_offsets[-1])
+        res[8: 8 + self.views + 1] = view_offsets
+        res[8 + self.views + 1:] = merged_ranges.reshape(-1)
+        if not flags:
+            res[4] = keys.shape[0]
+            vis_merged.numpy().view(np.uint32)[: merged.shape[0]] = merged
+            key_merged.numpy().view(np.uint64)[: keys.shape[0]] = keys

@@ -1,7 +1,9 @@
 """The device side of the multi-GPU exchange on one GPU: the G-way draw-key merge
 and the segmented copy that builds merged visible lists, fed (a) with synthetic
 runs and (b) with two shard contexts whose results are concatenated by hand in
-place of the all-gather; plus the real ShardExchange over RCCL with one rank."""
+place of the all-gather; the device-planned exchange (pack, plan, merge) checked
+against its numpy restatement and the whole-scene oracle, including blocks that
+are too small; plus the real ShardExchange over RCCL with one rank."""
 import os
 import socket
 
@@ -102,6 +104,101 @@ def test_two_shards_merge_to_the_whole_scene(oracle):
         hs.close()
 
 
+def _shard_scene(rank, n):
+    from vulkan_renderer_amd import synth
+    sc = synth.flat_scene(n, seed=9, first=rank * n, blend_fraction=0.3)
+    sc.pos[:, :3] *= np.float32(0.3)
+    return sc
+
+
+@pytest.mark.parametrize("world,cascades", [(2, 2), (3, 0)])
+def test_device_planned_exchange(oracle, world, cascades):
+    import torch
+    from helpers import numpy_exchange_merge, numpy_exchange_pack, oracle_frame, view_set
+    from vulkan_renderer_amd import HipScene, synth
+    from vulkan_renderer_amd.parallel import exchange_block_words, exchange_result_words
+    n = 30000
+    vs = synth.camera_views(cascades=cascades)
+    planes, required = view_set(vs)
+    v = planes.shape[0]
+    stream = torch.cuda.current_stream().cuda_stream
+    shards, refs = [], []
+    for rank in range(world):
+        sc = _shard_scene(rank, n)
+        hs = HipScene(max_nodes=n, max_candidates=n, max_views=v, source_index_base=rank * n)
+        hs.set_stream(stream)
+        hs.set_hierarchy(None, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        shards.append(hs)
+        refs.append(oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, index_base=rank * n))
+    need_vis = max(int(sum(int(st["visible_count"]) for st in ref["states"])) for ref in refs)
+    need_keys = max(ref["payload"]["sort_keys"].shape[0] for ref in refs)
+    assert need_vis > 200 and need_keys > 50
+
+    sc = synth.flat_scene(world * n, seed=9, blend_fraction=0.3)
+    sc.pos[:, :3] *= np.float32(0.3)
+    whole = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+
+    GUARD = 0x5a5a5a5a
+    for vis_cap, key_cap in ((need_vis + 13, need_keys + 3), (need_vis, need_keys),
+                             (need_vis // 2, need_keys + 3), (need_vis + 13, need_keys // 3)):
+        words = exchange_block_words(v, vis_cap, key_cap)
+        assert words == shards[0].exchange_block_words(v, vis_cap, key_cap)
+        assert exchange_result_words(v) == shards[0].exchange_result_words(v)
+        gathered = torch.full((world * words + 4,), GUARD, dtype=torch.int32, device="cuda")
+        for rank, hs in enumerate(shards):
+            hs.exchange_pack(gathered.data_ptr() + 4 * rank * words, vis_cap, key_cap)
+        merged_vis = torch.full((world * vis_cap + 4,), GUARD, dtype=torch.int32, device="cuda")
+        merged_keys = torch.full((world * key_cap + 4,), GUARD, dtype=torch.int64, device="cuda")
+        result = torch.zeros(exchange_result_words(v) + 1, dtype=torch.int64, device="cuda")
+        result[-1] = GUARD
+        shards[0].exchange_merge(gathered.data_ptr(), world, vis_cap, key_cap, merged_vis.data_ptr(),
+                                 merged_keys.data_ptr(), result.data_ptr())
+        torch.cuda.synchronize()
+        got_blocks = gathered.cpu().numpy().view(np.uint32)
+        assert (got_blocks[world * words:] == GUARD).all()
+        # every block equals the numpy restatement of the layout, byte for byte
+        # (words a short list leaves unused keep the fill value)
+        for rank, ref in enumerate(refs):
+            expect = numpy_exchange_pack(ref["states"], ref["visible"], ref["payload"]["sort_keys"], v,
+                                         vis_cap, key_cap)
+            got = got_blocks[rank * words: (rank + 1) * words]
+            written = got != GUARD
+            assert (got[written] == expect[written]).all(), f"rank {rank} block"
+            assert (expect[~written] == 0).all(), f"rank {rank}: a word that should be written is not"
+        flags, max_vis, max_keys, view_offsets, merged_ranges, exp_vis, exp_keys = numpy_exchange_merge(
+            oracle, np.where(got_blocks[: world * words] == GUARD, 0, got_blocks[: world * words]),
+            world, v, vis_cap, key_cap)
+        res = result.cpu().numpy().view(np.uint64)
+        assert int(res[-1]) == GUARD
+        assert int(res[0]) == flags == ((1 if vis_cap < need_vis else 0) | (2 if key_cap < need_keys else 0))
+        assert int(res[1]) == max_vis == need_vis and int(res[2]) == max_keys == need_keys
+        assert (merged_vis.cpu().numpy().view(np.uint32)[world * vis_cap:] == GUARD).all()
+        assert (merged_keys.cpu().numpy()[world * key_cap:] == GUARD).all()
+        if flags:
+            continue
+        assert (res[8: 8 + v + 1] == view_offsets).all()
+        assert (res[8 + v + 1: 8 + v + 1 + v * 8].reshape(v, 4, 2) == merged_ranges).all()
+        total_keys = int(res[4])
+        assert int(res[3]) == int(view_offsets[-1]) and total_keys == exp_keys.shape[0]
+        got_vis = merged_vis.cpu().numpy().view(np.uint32)
+        assert (got_vis[: exp_vis.shape[0]] == exp_vis).all()
+        got_keys = merged_keys.cpu().numpy().view(np.uint64)[:total_keys]
+        assert (got_keys == exp_keys).all()
+        # and both equal the single-process result on the whole scene
+        assert (got_keys == whole["payload"]["sort_keys"]).all()
+        for vi in range(v):
+            st = whole["states"][vi]
+            assert (merged_ranges[vi] == st["execution_ranges"]).all()
+            count, off = int(st["visible_count"]), int(view_offsets[vi])
+            assert (got_vis[off: off + count] == whole["visible"][vi, :count]).all(), f"view {vi}"
+    for hs in shards:
+        hs.close()
+
+
 def test_exchange_single_rank_over_rccl(oracle):
     """One rank, backend nccl (RCCL): the real HipShardSource plumbing end to end."""
     import torch
@@ -125,12 +222,18 @@ def test_exchange_single_rank_over_rccl(oracle):
             hs.upload_trs(sc.pos, sc.quat, sc.scale)
             hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
             hs.set_views(planes, required, vs.view)
-            ex = ShardExchange(hs, 1, 0, planes.shape[0])
-            for _ in range(2):
+            ex = ShardExchange(hs, 1, 0, planes.shape[0], vis_cap=256, key_cap=64)
+            for _ in range(3):
                 hs.mark_all(0x02)
                 hs.frame()
                 ex.run()
-            torch.cuda.synchronize()
+            ex.finish()
+            assert ex.regrown == 1
+            for _ in range(2):
+                hs.mark_all(0x02)
+                hs.frame()
+                ex.run().finish()
+            assert ex.regrown == 1
             keys = ex.key_merged.cpu().numpy().view(np.uint64)[: ex.transparent_total]
             assert (keys == ref["payload"]["sort_keys"]).all()
             vis = ex.vis_merged.cpu().numpy().view(np.uint32)

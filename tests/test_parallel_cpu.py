@@ -1,8 +1,9 @@
 """The multi-rank exchange on CPU: two `gloo` processes, each owning half of a
-scene, run the same ShardExchange code the GPU ranks run (header all-gather,
-merge plan, packed visible lists, key runs). Each rank's frame results come from
-the CPU oracle on its shard; the merged result must equal the oracle's result on
-the whole scene."""
+scene, run the same ShardExchange code the GPU ranks run (block pack, one
+all-gather, merge, capacity growth in finish()). Each rank's frame results come
+from the CPU oracle on its shard and the block layout is restated in numpy
+(helpers.py); the merged result must equal the oracle's result on the whole
+scene."""
 import os
 import socket
 import sys
@@ -65,53 +66,6 @@ def test_plan_visible_merge_matches_concatenation():
                 assert int(overflow[vi]) == dropped
 
 
-class _View:
-    def __init__(self, state):
-        self.execution_ranges = state["execution_ranges"]
-        self.visible_count = int(state["visible_count"])
-
-
-class _Info:
-    def __init__(self, states, t):
-        self.views = [_View(s) for s in states]
-        self.transparent_draw_count = t
-
-
-class OracleShardSource:
-    """One rank's frame results from the CPU oracle, in the shape ShardExchange asks for."""
-
-    def __init__(self, oracle, frame):
-        import torch
-        self.torch = torch
-        self.oracle = oracle
-        self.frame = frame
-        self.device = torch.device("cpu")
-
-    def frame_info(self):
-        return _Info(self.frame["states"], self.frame["payload"]["sort_keys"].shape[0])
-
-    def begin(self):
-        pass
-
-    def visible(self, view, count):
-        return self.torch.from_numpy(self.frame["visible"][view, :count].astype(np.int32))
-
-    def keys(self, count):
-        return self.torch.from_numpy(self.frame["payload"]["sort_keys"][:count].astype(np.int64))
-
-    def concat_ranges(self, gathered, merged, desc):
-        src = gathered.numpy()
-        dst = merged.numpy()
-        for s, d, c in desc.astype(np.int64):
-            dst[d:d + c] = src[s:s + c]
-
-    def merge_runs(self, gathered, run_stride, lengths, merged):
-        flat = gathered.numpy().view(np.uint64)
-        runs = [flat[r * run_stride: r * run_stride + int(lengths[r])] for r in range(lengths.shape[0])]
-        out = self.oracle.merge_runs_desc(runs)
-        merged.numpy().view(np.uint64)[: out.shape[0]] = out
-
-
 def _worker(rank, world, port, n_per_rank, result_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -119,7 +73,7 @@ def _worker(rank, world, port, n_per_rank, result_dir):
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    from helpers import oracle_frame, view_set
+    from helpers import OracleShardSource, oracle_frame, view_set
     from oracle import pyoracle
     from vulkan_renderer_amd import synth
     from vulkan_renderer_amd.parallel import ShardExchange
@@ -132,12 +86,15 @@ def _worker(rank, world, port, n_per_rank, result_dir):
         sc.pos[:, :3] *= np.float32(0.3)  # denser: every rank contributes to every bucket
         frame = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection,
                              index_base=rank * n_per_rank)
-        ex = ShardExchange(OracleShardSource(oracle, frame), world, rank, planes.shape[0],
-                           device=torch.device("cpu"))
-        for _ in range(2):  # second run reuses the grown buffers
-            ex.run()
+        # small starting capacities: the first finish() has to grow and repeat
+        ex = ShardExchange(OracleShardSource(oracle, frame, planes.shape[0]), world, rank,
+                           planes.shape[0], device=torch.device("cpu"), vis_cap=64, key_cap=16)
+        ex.run().finish()
+        regrown = ex.regrown
+        ex.run().finish()  # second frame reuses the grown buffers
+        assert ex.regrown == regrown >= 1
         np.savez(os.path.join(result_dir, f"rank{rank}.npz"),
-                 vis=ex.vis_merged.numpy()[: int(ex.view_offsets[-1])].astype(np.uint32),
+                 vis=ex.vis_merged.numpy()[: int(ex.view_offsets[-1])].view(np.uint32),
                  keys=ex.key_merged.numpy().view(np.uint64)[: ex.transparent_total],
                  merged_ranges=ex.merged_ranges, view_offsets=ex.view_offsets)
     finally:

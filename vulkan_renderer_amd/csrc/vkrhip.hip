@@ -20,6 +20,7 @@
 #include "k_cull.hpp"
 #include "k_fused.hpp"
 #include "k_pack.hpp"
+#include "k_exchange.hpp"
 #include "k_sort.hpp"
 #include "k_transform.hpp"
 
@@ -145,6 +146,8 @@ struct vkrhip_ctx {
   DevBuf<const uint64_t *> merge_ptrs;
   DevBuf<uint64_t> merge_lens;
   DevBuf<uint64_t> concat_desc;
+  // device-planned exchange
+  DevBuf<uint64_t> exch_desc, exch_rank_view_start, exch_prefix, exch_runs;
 
   // timing
   uint32_t profiling = 0;  // bit i: time stage i
@@ -434,6 +437,10 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->merge_ptrs);
   dev_free(c->merge_lens);
   dev_free(c->concat_desc);
+  dev_free(c->exch_desc);
+  dev_free(c->exch_rank_view_start);
+  dev_free(c->exch_prefix);
+  dev_free(c->exch_runs);
   if (c->host_hint) (void)hipHostFree(c->host_hint);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1418,6 +1425,73 @@ int vkrhip_merge_runs(vkrhip_ctx *c, uint32_t g, const uint64_t *const *runs_key
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, c->stream,
                      c->merge_ptrs.p, c->merge_lens.p, g, total, out_keys_dev);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+uint64_t vkrhip_exchange_block_words(uint32_t views, uint32_t vis_cap, uint32_t key_cap) {
+  return exchange_block_words(views, vis_cap, key_cap);
+}
+
+uint64_t vkrhip_exchange_result_words(uint32_t views) { return exchange_result_words(views); }
+
+int vkrhip_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap) {
+  if (!c || !block_dev) return VKRHIP_ERR_ARG;
+  if (!c->frame_ran || !(c->last_stages & VKRHIP_STAGE_CULL))
+    return fail(c, VKRHIP_ERR_STATE, "exchange needs a frame that ran the cull stage");
+  TRY(bind_device(c));
+  ExchangePackArgs a{};
+  a.states = c->states.p;
+  a.visible = c->visible.p;
+  a.keys = c->out_keys.p;
+  a.counters = c->counters();
+  a.block = block_dev;
+  a.visible_stride = c->visible_stride;
+  a.views = c->views;
+  a.vis_cap = vis_cap;
+  a.key_cap = key_cap;
+  a.have_keys = (c->last_stages & VKRHIP_STAGE_TRANSPARENT) && c->out_keys.p ? 1u : 0u;
+  const uint64_t widest = std::max<uint64_t>(std::max(vis_cap, key_cap), 1);
+  const unsigned blocks = (unsigned)std::min<uint64_t>(ceil_div(widest, 1024), 512);
+  hipLaunchKernelGGL(k_exchange_pack, dim3(blocks, c->views + 1u), dim3(256), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+int vkrhip_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t world,
+                          uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
+                          uint64_t *merged_keys_dev, uint64_t *result_dev) {
+  if (!c || !gathered_dev || !merged_visible_dev || !merged_keys_dev || !result_dev)
+    return VKRHIP_ERR_ARG;
+  if (world == 0 || world > 64) return fail(c, VKRHIP_ERR_ARG, "world size %u outside 1..64", world);
+  if (c->views == 0) return fail(c, VKRHIP_ERR_STATE, "no views set");
+  TRY(bind_device(c));
+  const uint32_t pairs = c->views * 4u;
+  TRY(dev_alloc(c, c->exch_desc, (size_t)pairs * world * 3));
+  TRY(dev_alloc(c, c->exch_rank_view_start, (size_t)world * c->views));
+  TRY(dev_alloc(c, c->exch_prefix, (size_t)pairs + 1));
+  TRY(dev_alloc(c, c->exch_runs, 128));
+  ExchangePlanArgs a{};
+  a.gathered = gathered_dev;
+  a.desc = c->exch_desc.p;
+  a.rank_view_start = c->exch_rank_view_start.p;
+  a.prefix = c->exch_prefix.p;
+  a.runs = c->exch_runs.p;
+  a.result = result_dev;
+  a.world = world;
+  a.views = c->views;
+  a.vis_cap = vis_cap;
+  a.key_cap = key_cap;
+  hipLaunchKernelGGL(k_exchange_plan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, a);
+  // copy rows: enough blocks per descriptor to cover the largest possible range
+  const unsigned rows = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vis_cap, 4096), 1), 64);
+  hipLaunchKernelGGL(k_concat_ranges, dim3(pairs * world, rows), dim3(256), 0, c->stream, gathered_dev,
+                     merged_visible_dev, c->exch_desc.p);
+  if (key_cap) {
+    const uint64_t most = (uint64_t)world * key_cap;
+    hipLaunchKernelGGL(k_exchange_merge_keys, dim3((unsigned)ceil_div(most, 256)), dim3(256), 0,
+                       c->stream, gathered_dev, c->exch_runs.p, world, merged_keys_dev);
+  }
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }

@@ -3,22 +3,29 @@
 Instances are sharded by contiguous range: rank g owns global candidate indices
 [g*n, (g+1)*n) and the transform subtrees they hang from, so transform, cull and
 the local sort need no communication. The only exchange step is after the
-frame:
+frame, and it is enqueued without a host round trip:
 
-1. all-gather of every rank's per-view compaction states and transparent count
-   (a few hundred bytes);
-2. all-gather of the packed visible lists (RCCL over xGMI; `nccl` backend);
-   because rank order is index order, the merged list of a (view, bucket) is the
-   concatenation of the ranks' ranges - built by one segmented-copy kernel from
-   a descriptor table (`plan_visible_merge`);
-3. all-gather of the sorted draw-key runs, merged by the G-way rank merge kernel.
+1. every rank packs one block at fixed capacities: a header (the execution
+   ranges of every view, the draw count), its visible lists back to back and
+   its sorted draw-key run (`vkrhip_exchange_pack`);
+2. ONE all-gather of the blocks (RCCL over xGMI; `nccl` backend);
+3. a planning kernel reads the gathered headers on the device and the merged
+   lists follow: rank order is index order, so the merged list of a (view,
+   bucket) is the concatenation of the ranks' ranges (one segmented-copy
+   kernel), and the draw keys are a G-way rank merge (`vkrhip_exchange_merge`).
+
+The host looks at the result words only in finish(): a rank whose lists did not
+fit the capacities is flagged there, every rank sees the same flags and grows
+its buffers alike, and the exchange of that frame is repeated.
 
 The reference is single-GPU; nothing here has a counterpart in it. The
-collectives are plain torch.distributed calls, so the same exchange runs on
-`gloo` with CPU tensors in the tests (the two device kernels are then served by
-a numpy-backed source, see tests/test_parallel_cpu.py).
+collective is a plain torch.distributed call, so the same exchange runs on
+`gloo` with CPU tensors in the tests (pack and merge are then served by a
+numpy-backed source, see tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
+
+import contextlib
 
 import numpy as np
 
@@ -97,6 +104,27 @@ def apply_descriptors(gathered: np.ndarray, rank_stride: int, desc: np.ndarray, 
     return out
 
 
+# ---- block layout (mirrors include/vkr_hip_scene.h, vkrhip_exchange_*) ------
+def _round_up4(x: int) -> int:
+    return (int(x) + 3) & ~3
+
+
+def exchange_header_words(views: int) -> int:
+    return _round_up4(views * 8 + 4)
+
+
+def exchange_block_words(views: int, vis_cap: int, key_cap: int) -> int:
+    return exchange_header_words(views) + _round_up4(vis_cap) + _round_up4(key_cap * 2)
+
+
+RESULT_FIXED_WORDS = 8
+FLAG_VISIBLE_TRUNCATED, FLAG_KEYS_TRUNCATED, FLAG_HEADER_MISMATCH = 1, 2, 4
+
+
+def exchange_result_words(views: int) -> int:
+    return RESULT_FIXED_WORDS + views + 1 + views * 8
+
+
 class _DevicePointer:
     """Zero-copy view of library-owned HBM for torch (`__cuda_array_interface__`)."""
 
@@ -114,48 +142,49 @@ def wrap_device(ptr: int, count: int, dtype):
 
 
 class HipShardSource:
-    """What ShardExchange needs from one rank's scene, served from the HIP
-    library's device buffers (zero-copy torch views) and its two merge kernels."""
+    """One rank's scene as ShardExchange sees it. The scene's frames, pack, merge
+    and the collective all go to one torch stream owned by this object (the
+    library treats a null stream handle as "use a private stream", which torch's
+    default stream is), so they are ordered without any host wait."""
 
     def __init__(self, scene):
         import torch
         self.torch = torch
         self.scene = scene
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(device=self.device)
+        scene.set_stream(self.stream.cuda_stream)
 
-    def frame_info(self):
-        return self.scene.frame_info()  # waits for the frame; scalar results on the host
+    def stream_scope(self):
+        return self.torch.cuda.stream(self.stream)
 
-    def begin(self):
-        self.out = self.scene.device_outputs()
+    def pack(self, block, vis_cap: int, key_cap: int):
+        self.scene.exchange_pack(block.data_ptr(), vis_cap, key_cap)
 
-    def visible(self, view: int, count: int):
-        return wrap_device(self.out.visible + 4 * view * self.out.visible_stride, count,
-                           self.torch.int32)
-
-    def keys(self, count: int):
-        return wrap_device(self.out.transparent_keys, count, self.torch.int64)
-
-    def concat_ranges(self, gathered, merged, desc: np.ndarray):
-        self.scene.concat_ranges(gathered.data_ptr(), merged.data_ptr(), desc)
-
-    def merge_runs(self, gathered, run_stride: int, lengths: np.ndarray, merged):
-        ptrs = [gathered.data_ptr() + 8 * r * run_stride for r in range(lengths.shape[0])]
-        self.scene.merge_runs(ptrs, lengths, merged.data_ptr())
+    def merge(self, gathered, world: int, vis_cap: int, key_cap: int, vis_merged, key_merged, result):
+        self.scene.exchange_merge(gathered.data_ptr(), world, vis_cap, key_cap, vis_merged.data_ptr(),
+                                  key_merged.data_ptr(), result.data_ptr())
 
 
 class ShardExchange:
     """Per-frame exchange of one rank's results with the other ranks.
 
-    `source` provides this rank's frame results and the two merge primitives
-    (HipShardSource on a GPU; the CPU tests pass a numpy-backed stand-in and run
-    the same exchange over `gloo`). After run(): vis_merged holds, view after
-    view, the merged visible list of every (view, bucket) (merged_ranges /
-    view_offsets describe it) and key_merged[:transparent_total] the merged
-    descending draw keys - identical on every rank.
+    `source` provides pack() and merge() for this rank's frame (HipShardSource on
+    a GPU; the CPU tests pass a numpy-backed stand-in and run the same exchange
+    over `gloo`). run() only enqueues; finish() waits, validates the capacities
+    (growing them and repeating the exchange when a rank overflowed) and fills
+    merged_ranges / view_offsets / visible_total / transparent_total. After
+    finish(): vis_merged holds, view after view, the merged visible list of
+    every (view, bucket) and key_merged[:transparent_total] the merged descending
+    draw keys - identical on every rank.
+
+    Every rank must call run() and finish() in the same order: the capacities
+    change only in finish(), from values every rank reads out of the same
+    gathered headers, so the all-gather sizes always agree.
     """
 
-    def __init__(self, source, world: int, rank: int, views: int, group=None, device=None):
+    def __init__(self, source, world: int, rank: int, views: int, group=None, device=None,
+                 vis_cap: int = 4096, key_cap: int = 1024):
         import torch
         self.torch = torch
         from .scene import HipScene
@@ -164,74 +193,61 @@ class ShardExchange:
         self.source = source
         self.world, self.rank, self.views, self.group = world, rank, views, group
         self.device = device if device is not None else source.device
-        self.hdr_len = views * 8 + 2
-        self.hdr_send = torch.zeros(self.hdr_len, dtype=torch.int64, device=self.device)
-        self.hdr_recv = torch.zeros(world * self.hdr_len, dtype=torch.int64, device=self.device)
-        self.vis_cap = 0
-        self.key_cap = 0
-        self.vis_send = self.vis_recv = self.vis_merged = None
-        self.key_send = self.key_recv = self.key_merged = None
+        self.regrown = 0
         self.merged_ranges = None
         self.view_offsets = None
+        self.visible_total = 0
         self.transparent_total = 0
+        scope = getattr(source, "stream_scope", None)
+        self._scope = scope if scope is not None else contextlib.nullcontext
+        with self._scope():
+            self.result = torch.zeros(exchange_result_words(views), dtype=torch.int64, device=self.device)
+            self._alloc(vis_cap, key_cap)
 
-    def _grow(self, vis_need: int, key_need: int, merged_vis: int, merged_keys: int):
-        # every rank sees the same gathered header, so all ranks grow alike and the
-        # all-gather buffers keep equal sizes
+    def _alloc(self, vis_cap: int, key_cap: int):
         torch = self.torch
-        if vis_need > self.vis_cap or self.vis_send is None:
-            self.vis_cap = max(int(vis_need * 1.25) + 1024, 1024)
-            self.vis_send = torch.zeros(self.vis_cap, dtype=torch.int32, device=self.device)
-            self.vis_recv = torch.zeros(self.world * self.vis_cap, dtype=torch.int32, device=self.device)
-        if key_need > self.key_cap or self.key_send is None:
-            self.key_cap = max(int(key_need * 1.25) + 1024, 1024)
-            self.key_send = torch.zeros(self.key_cap, dtype=torch.int64, device=self.device)
-            self.key_recv = torch.zeros(self.world * self.key_cap, dtype=torch.int64, device=self.device)
-        if self.vis_merged is None or self.vis_merged.numel() < merged_vis:
-            self.vis_merged = torch.zeros(int(merged_vis * 1.25) + 1024, dtype=torch.int32,
-                                          device=self.device)
-        if self.key_merged is None or self.key_merged.numel() < merged_keys:
-            self.key_merged = torch.zeros(int(merged_keys * 1.25) + 1024, dtype=torch.int64,
-                                          device=self.device)
+        self.vis_cap, self.key_cap = _round_up4(max(vis_cap, 4)), _round_up4(max(key_cap, 4))
+        words = exchange_block_words(self.views, self.vis_cap, self.key_cap)
+        self.send = torch.zeros(words, dtype=torch.int32, device=self.device)
+        self.recv = torch.zeros(self.world * words, dtype=torch.int32, device=self.device)
+        self.vis_merged = torch.zeros(self.world * self.vis_cap, dtype=torch.int32, device=self.device)
+        self.key_merged = torch.zeros(self.world * self.key_cap, dtype=torch.int64, device=self.device)
 
     def run(self):
-        torch, dist = self.torch, self.torch.distributed
-        src, v, g = self.source, self.views, self.world
-        info = src.frame_info()
-        hdr = np.zeros(self.hdr_len, np.int64)
-        for vi, st in enumerate(info.views):
-            hdr[vi * 8: vi * 8 + 8] = np.asarray(st.execution_ranges).reshape(-1)
-        hdr[v * 8] = info.transparent_draw_count
-        self.hdr_send.copy_(torch.from_numpy(hdr))
-        dist.all_gather_into_tensor(self.hdr_recv, self.hdr_send, group=self.group)
-        all_hdr = self.hdr_recv.cpu().numpy().reshape(g, self.hdr_len)
-        ranges = all_hdr[:, : v * 8].reshape(g, v, 4, 2).astype(np.uint64)
-        t_all = all_hdr[:, v * 8].astype(np.uint64)
-        vis_counts = ranges[..., 1].sum(axis=(1, 2))
-        desc, merged_ranges, view_offsets, _ = plan_visible_merge(ranges)
-        self._grow(int(vis_counts.max()), int(t_all.max()), int(view_offsets[-1]), int(t_all.sum()))
+        """Enqueue pack, all-gather and merge of the frame that was just enqueued."""
+        dist = self.torch.distributed
+        with self._scope():
+            self.source.pack(self.send, self.vis_cap, self.key_cap)
+            if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+                self.recv.copy_(self.send, non_blocking=True)
+            else:
+                dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            self.source.merge(self.recv, self.world, self.vis_cap, self.key_cap, self.vis_merged,
+                              self.key_merged, self.result)
+        return self
 
-        src.begin()
-        # pack this rank's views back to back
-        pos = 0
-        for vi, st in enumerate(info.views):
-            cnt = int(st.visible_count)
-            if cnt:
-                self.vis_send[pos: pos + cnt].copy_(src.visible(vi, cnt), non_blocking=True)
-            pos += cnt
-        dist.all_gather_into_tensor(self.vis_recv, self.vis_send, group=self.group)
-        t_local = int(info.transparent_draw_count)
-        if t_local:
-            self.key_send[:t_local].copy_(src.keys(t_local), non_blocking=True)
-        dist.all_gather_into_tensor(self.key_recv, self.key_send, group=self.group)
-
-        # merged visible lists: one segmented copy; descriptor k of a (view, bucket)
-        # belongs to rank k % g, whose packed list starts at rank * vis_cap
-        desc_abs = desc.copy()
-        desc_abs[:, 0] += (np.arange(desc.shape[0], dtype=np.uint64) % np.uint64(g)) * np.uint64(self.vis_cap)
-        src.concat_ranges(self.vis_recv, self.vis_merged, desc_abs)
-        # merged draw keys: G-way merge of the descending runs
-        src.merge_runs(self.key_recv, self.key_cap, t_all, self.key_merged)
-        self.merged_ranges, self.view_offsets = merged_ranges, view_offsets
-        self.transparent_total = int(t_all.sum())
+    def finish(self):
+        """Wait for the exchange, repeat it with larger blocks if a rank overflowed."""
+        v = self.views
+        while True:
+            with self._scope():
+                res = self.result.cpu().numpy().view(np.uint64)  # waits for the stream
+            flags = int(res[0])
+            if flags & FLAG_HEADER_MISMATCH:
+                raise RuntimeError("exchange blocks were packed for different view counts")
+            if not flags & (FLAG_VISIBLE_TRUNCATED | FLAG_KEYS_TRUNCATED):
+                break
+            vis_cap, key_cap = self.vis_cap, self.key_cap
+            if int(res[1]) > vis_cap:
+                vis_cap = int(int(res[1]) * 1.25) + 1024
+            if int(res[2]) > key_cap:
+                key_cap = int(int(res[2]) * 1.25) + 1024
+            with self._scope():
+                self._alloc(vis_cap, key_cap)
+            self.regrown += 1
+            self.run()
+        self.visible_total = int(res[3])
+        self.transparent_total = int(res[4])
+        self.view_offsets = res[RESULT_FIXED_WORDS: RESULT_FIXED_WORDS + v + 1].copy()
+        self.merged_ranges = res[RESULT_FIXED_WORDS + v + 1:].reshape(v, 4, 2).copy()
         return self

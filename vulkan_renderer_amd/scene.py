@@ -363,6 +363,22 @@ class HipScene:
                                                desc.shape[0]))
 
 
+    # ---- multi-GPU exchange planned on the device --------------------------
+    def exchange_block_words(self, views: int, vis_cap: int, key_cap: int) -> int:
+        return int(self.lib.vkrhip_exchange_block_words(views, vis_cap, key_cap))
+
+    def exchange_result_words(self, views: int) -> int:
+        return int(self.lib.vkrhip_exchange_result_words(views))
+
+    def exchange_pack(self, block_ptr: int, vis_cap: int, key_cap: int) -> None:
+        self._ok(self.lib.vkrhip_exchange_pack(self.ctx, block_ptr, vis_cap, key_cap))
+
+    def exchange_merge(self, gathered_ptr: int, world: int, vis_cap: int, key_cap: int,
+                       merged_visible_ptr: int, merged_keys_ptr: int, result_ptr: int) -> None:
+        self._ok(self.lib.vkrhip_exchange_merge(self.ctx, gathered_ptr, world, vis_cap, key_cap,
+                                                merged_visible_ptr, merged_keys_ptr, result_ptr))
+
+
 # ---- host-side leaf mirrors ---------------------------------------------
 def frustum_from_matrix(view_projection) -> np.ndarray:
     """vkr_frustum_from_matrix (lib/src/math/vkr_frustum.c:44-66)."""
