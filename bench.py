@@ -118,10 +118,17 @@ def main() -> int:
                          "(default); local = every node's TRS changed, locals are rebuilt too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend; gloo lets several ranks rehearse on one GPU")
     ap.add_argument("--exchange", action="store_true",
                     help="run the multi-GPU exchange step even with one rank (to time its launches)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
+
+    watchdog = float(os.environ.get("VKR_BENCH_WATCHDOG", "0"))
+    if watchdog > 0:  # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(watchdog, exit=True)
 
     import torch
     import torch.distributed as dist
@@ -137,11 +144,16 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
+    if args.backend == "gloo":  # rehearsal: ranks may share a GPU
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from vulkan_renderer_amd import HipScene, build_view_set, frustum_from_matrix
     from vulkan_renderer_amd import _native as N

@@ -183,6 +183,10 @@ const char *vkrhip_last_error(const vkrhip_ctx *ctx);
 /* Run all work of this context on an existing hipStream_t (NULL restores the
  * context's own stream). */
 int vkrhip_set_stream(vkrhip_ctx *ctx, void *hip_stream);
+/* The hipStream_t the context currently enqueues on (its own stream unless
+ * vkrhip_set_stream changed it), for callers that want to order their own work
+ * (copies, collectives) with the context's. */
+void *vkrhip_get_stream(const vkrhip_ctx *ctx);
 int vkrhip_sync(vkrhip_ctx *ctx);
 
 /* ---- scene state: replaces the SceneTransform column walked by

@@ -243,3 +243,68 @@ def test_exchange_single_rank_over_rccl(oracle):
                 assert (vis[off: off + count] == ref["visible"][vi, :count]).all()
     finally:
         dist.destroy_process_group()
+
+
+def _gloo_worker(rank, world, port, n, result_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from helpers import view_set
+    from vulkan_renderer_amd import HipScene, synth
+    from vulkan_renderer_amd.parallel import ShardExchange
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vs = synth.camera_views(cascades=2)
+        planes, required = view_set(vs)
+        sc = _shard_scene(rank, n)
+        with HipScene(max_nodes=n, max_candidates=n, max_views=planes.shape[0],
+                      source_index_base=rank * n) as hs:
+            hs.set_hierarchy(None, sc.level_offsets)
+            hs.upload_trs(sc.pos, sc.quat, sc.scale)
+            hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+            hs.set_views(planes, required, vs.view)
+            ex = ShardExchange(hs, world, rank, planes.shape[0], vis_cap=128, key_cap=32)
+            for _ in range(3):
+                hs.mark_all(0x02)
+                hs.frame()
+                ex.run()
+            ex.finish()
+            np.savez(os.path.join(result_dir, f"rank{rank}.npz"),
+                     vis=ex.vis_merged.cpu().numpy().view(np.uint32)[: ex.visible_total],
+                     keys=ex.key_merged.cpu().numpy().view(np.uint64)[: ex.transparent_total],
+                     merged_ranges=ex.merged_ranges, view_offsets=ex.view_offsets,
+                     regrown=np.array([ex.regrown]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_over_gloo(oracle, tmp_path):
+    """Two ranks as two processes (both on this GPU, collective over gloo): the
+    whole per-rank flow of a multi-GPU run except the RCCL transport."""
+    import torch.multiprocessing as mp
+    from helpers import oracle_frame, view_set
+    from vulkan_renderer_amd import synth
+    world, n = 2, 20000
+    mp.spawn(_gloo_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    vs = synth.camera_views(cascades=2)
+    planes, required = view_set(vs)
+    sc = synth.flat_scene(world * n, seed=9, blend_fraction=0.3)
+    sc.pos[:, :3] *= np.float32(0.3)
+    whole = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    results = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for name in ("vis", "keys", "merged_ranges", "view_offsets", "regrown"):
+        assert (results[0][name] == results[1][name]).all(), f"ranks disagree on {name}"
+    r0 = results[0]
+    assert int(r0["regrown"][0]) >= 1
+    assert (r0["keys"] == whole["payload"]["sort_keys"]).all()
+    for v in range(planes.shape[0]):
+        st = whole["states"][v]
+        assert (r0["merged_ranges"][v] == st["execution_ranges"]).all()
+        count, off = int(st["visible_count"]), int(r0["view_offsets"][v])
+        assert (r0["vis"][off: off + count] == whole["visible"][v, :count]).all()

@@ -454,6 +454,8 @@ int vkrhip_set_stream(vkrhip_ctx *c, void *hip_stream) {
   return VKRHIP_OK;
 }
 
+void *vkrhip_get_stream(const vkrhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 int vkrhip_sync(vkrhip_ctx *c) {
   if (!c) return VKRHIP_ERR_ARG;
   TRY(bind_device(c));

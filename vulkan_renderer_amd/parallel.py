@@ -142,18 +142,20 @@ def wrap_device(ptr: int, count: int, dtype):
 
 
 class HipShardSource:
-    """One rank's scene as ShardExchange sees it. The scene's frames, pack, merge
-    and the collective all go to one torch stream owned by this object (the
-    library treats a null stream handle as "use a private stream", which torch's
-    default stream is), so they are ordered without any host wait."""
+    """One rank's scene as ShardExchange sees it. Pack, merge and the collective
+    are enqueued on the stream the scene itself runs on (wrapped for torch as an
+    external stream), so they are ordered with the frame without any host wait.
+    A scene that was pointed at torch's default stream gets its own stream back:
+    the library reads a null handle as "use the private stream"."""
 
     def __init__(self, scene):
         import torch
         self.torch = torch
         self.scene = scene
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.stream = torch.cuda.Stream(device=self.device)
-        scene.set_stream(self.stream.cuda_stream)
+        if scene.stream_handle() == 0:
+            scene.set_stream(None)
+        self.stream = torch.cuda.ExternalStream(scene.stream_handle(), device=self.device)
 
     def stream_scope(self):
         return self.torch.cuda.stream(self.stream)

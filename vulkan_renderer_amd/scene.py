@@ -153,6 +153,10 @@ class HipScene:
     def set_stream(self, hip_stream: int | None) -> None:
         self._ok(self.lib.vkrhip_set_stream(self.ctx, hip_stream))
 
+    def stream_handle(self) -> int:
+        """hipStream_t the context enqueues on (its own stream by default)."""
+        return int(self.lib.vkrhip_get_stream(self.ctx) or 0)
+
     def sync(self) -> None:
         self._ok(self.lib.vkrhip_sync(self.ctx))
 
