@@ -397,23 +397,28 @@ __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
 
 // Sort + emission in one launch for small counts. Sort keys are unique (the low
 // word is the source row), so the output row of a key is simply the number of
-// keys greater than it. Every block stages the key array in LDS; a wave takes
-// RANK_WAVE_KEYS keys at a time and sweeps the whole array past them, 64 keys
-// per step, one compare + ballot population count per (key, step); its 64 lanes
-// then write the eight 16-byte pieces of the eight rows. count^2 / 64 compares:
-// 1M wave-steps at 8192 keys, spread over every CU that got a block, against
-// four passes of barriers and LDS atomics on one CU for a radix sort.
+// keys greater than it. A block takes RANK_BLOCK_KEYS keys; its eight waves
+// split the key array between them and sweep their stretch past the block's
+// keys, 64 keys per load, one compare + ballot population count per (key,
+// load); the partial counts meet in LDS and two waves write the eight 16-byte
+// pieces of the sixteen rows. The sweep reads the array straight from L2 (every
+// wave load is 512 consecutive bytes) - no copy of the whole array per block, no
+// barrier before the sweep. count^2 / 64 compares: 1M wave-steps at 8192 keys,
+// spread over every CU, against four passes of barriers and LDS atomics on one
+// CU for a radix sort.
 //
 // Above RANK_LIMIT keys the quadratic sweep is not started: block 0 alone sorts
 // by streaming radix passes through global memory and emits every row. That
 // only happens when the host launched this kernel on a stale small estimate of
 // the count; it is correct, but runs at one CU's bandwidth.
-constexpr int RANK_WAVE_KEYS = 8;
+constexpr int RANK_BLOCK_KEYS = 16;
+constexpr int RANK_LOADS = 4;  // sweep loads in flight per wave
 constexpr uint32_t RANK_LIMIT = SMALL_KEYS;
 
 __global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_t *keys,
                                                              uint64_t *scratch) {
-  __shared__ SmallSortShared s;  // keys[0]: the staged key array; all of it: the fallback
+  __shared__ SmallSortShared s;  // the fallback's staging
+  __shared__ uint32_t s_part[SMALL_WAVES][RANK_BLOCK_KEYS];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   if (count == 0) return;
   const uint32_t t = threadIdx.x;
@@ -433,50 +438,60 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_
     return;
   }
 
-  // every block keeps a copy of the key array in LDS: one round of coalesced
-  // loads instead of a global-memory round trip per sweep step
-  uint64_t *all = s.keys[0];
-  for (uint32_t k = t; k < count; k += SMALL_THREADS) all[k] = keys[k];
-  for (uint32_t k = count + t; k < ((count + 255u) & ~255u); k += SMALL_THREADS)
-    all[k] = 0ull;  // padding of the last sweep step; sort keys are >= 1
-  __syncthreads();
-
   const uint32_t lane = t & 63u;
-  const uint32_t waves = gridDim.x * (SMALL_THREADS / 64u);
-  const uint32_t groups = (count + RANK_WAVE_KEYS - 1u) / RANK_WAVE_KEYS;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));  // keeps g scalar
-  for (uint32_t g = blockIdx.x * (SMALL_THREADS / 64u) + wave; g < groups; g += waves) {
-    // the wave's own keys, broadcast LDS reads; slots past the end repeat the
-    // last key (they are not emitted)
-    uint64_t mine[RANK_WAVE_KEYS];
-    uint32_t greater[RANK_WAVE_KEYS];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+  // the wave's stretch of the array: an eighth of it, in whole 64-key loads
+  const uint32_t per_wave = ((count + 64u * SMALL_WAVES - 1u) / (64u * SMALL_WAVES)) * 64u;
+  const uint32_t lo = wave * per_wave;
+  const uint32_t hi = min(lo + per_wave, count);
+  const uniform_ptr<uint64_t> block_keys = as_uniform(keys);  // nothing writes keys[] on this path
+  const uint32_t groups = (count + RANK_BLOCK_KEYS - 1u) / RANK_BLOCK_KEYS;
+  for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    // the block's keys, scalar loads; slots past the end repeat the last key
+    // (they are not emitted)
+    uint64_t mine[RANK_BLOCK_KEYS];
+    uint32_t greater[RANK_BLOCK_KEYS];
 #pragma unroll
-    for (int k = 0; k < RANK_WAVE_KEYS; ++k) {
-      const uint32_t i = g * RANK_WAVE_KEYS + (uint32_t)k;
-      mine[k] = all[min(i, count - 1u)];
+    for (int k = 0; k < RANK_BLOCK_KEYS; ++k) {
+      mine[k] = block_keys[min(g * RANK_BLOCK_KEYS + (uint32_t)k, count - 1u)];
       greater[k] = 0u;
     }
-    // lane = 8 * key slot + piece: its piece of its row is gathered while the
-    // sweep below works out where the row goes
-    const uint32_t own = min(g * RANK_WAVE_KEYS + (lane >> 3), count - 1u);
-    const uint64_t own_key = all[own];
-    const uint4 own_piece = emit_piece_gather(a, own_key, lane & 7u);
-    for (uint32_t base = 0; base < count; base += 256u) {
-      uint64_t other[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) other[u] = all[base + (uint32_t)u * 64u + lane];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < RANK_WAVE_KEYS; ++k)
-          greater[k] += (uint32_t)__popcll(__ballot(other[u] > mine[k]));
+    // waves 0 and 1 emit: lane = 8 * row slot + piece; the piece is gathered
+    // while the sweep works out where the row goes
+    const uint32_t slot = wave * 8u + (lane >> 3);
+    uint64_t own_key = 0ull;
+    uint4 own_piece = make_uint4(0u, 0u, 0u, 0u);
+    if (wave < RANK_BLOCK_KEYS / 8) {
+      own_key = keys[min(g * RANK_BLOCK_KEYS + slot, count - 1u)];
+      own_piece = emit_piece_gather(a, own_key, lane & 7u);
     }
-    const uint32_t slot = lane >> 3;
-    uint32_t row = 0u;
+    for (uint32_t base = lo; base < hi; base += 64u * RANK_LOADS) {
+      uint64_t other[RANK_LOADS];
+      uint64_t inside[RANK_LOADS];
 #pragma unroll
-    for (int k = 0; k < RANK_WAVE_KEYS; ++k)
-      if (slot == (uint32_t)k) row = greater[k];
-    if (g * RANK_WAVE_KEYS + slot < count) emit_piece_store(a, row, own_key, lane & 7u, own_piece);
+      for (int u = 0; u < RANK_LOADS; ++u) {
+        const uint32_t i = base + (uint32_t)u * 64u + lane;
+        other[u] = keys[min(i, count - 1u)];
+        inside[u] = __ballot(i < hi);
+      }
+#pragma unroll
+      for (int u = 0; u < RANK_LOADS; ++u)
+#pragma unroll
+        for (int k = 0; k < RANK_BLOCK_KEYS; ++k)
+          greater[k] += (uint32_t)__popcll(__ballot(other[u] > mine[k]) & inside[u]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < RANK_BLOCK_KEYS; ++k) s_part[wave][k] = greater[k];
+    }
+    __syncthreads();
+    if (wave < RANK_BLOCK_KEYS / 8) {
+      uint32_t row = 0u;
+#pragma unroll
+      for (int w = 0; w < SMALL_WAVES; ++w) row += s_part[w][slot];
+      if (g * RANK_BLOCK_KEYS + slot < count) emit_piece_store(a, row, own_key, lane & 7u, own_piece);
+    }
+    __syncthreads();  // s_part is reused by the next group
   }
 }
 

@@ -1039,8 +1039,7 @@ static int launch_transparent(vkrhip_ctx *c) {
   if (hint != 0u) expected = std::min<uint64_t>(cap, (uint64_t)(hint - 1u) * 5u / 4u + 256u);
   if (expected <= RANK_LIMIT) {
     StageTimer timer(c, VKRHIP_TIMER_SORT);
-    const unsigned grid = (unsigned)std::max<uint64_t>(
-        1, ceil_div(expected, (uint64_t)RANK_WAVE_KEYS * (SMALL_THREADS / 64)));
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, ceil_div(expected, (uint64_t)RANK_BLOCK_KEYS));
     hipLaunchKernelGGL(k_rank_emit, dim3(grid), dim3(SMALL_THREADS), 0, c->stream, emit_args(c),
                        c->keys_a.p, c->keys_b.p);
     HIP_TRY(c, hipGetLastError());
