@@ -298,6 +298,16 @@ int vkrhip_merge_runs(vkrhip_ctx *ctx, uint32_t g, const uint64_t *const *runs_k
 int vkrhip_concat_ranges(vkrhip_ctx *ctx, const uint32_t *src_dev, uint32_t *dst_dev,
                          const uint64_t *desc, uint32_t n_desc);
 
+/* ---- candidate epoch (replaces vkr_vk_candidate_epoch,
+ * lib/src/renderer/vulkan/vkr_vulkan_draws.c:9-44) -----------------------------
+ * 64-bit FNV-1a over mesh, geometry, submesh_index, material, instance.model,
+ * local_bounding_sphere, state_bucket and flags of every CAMERA_OPAQUE source
+ * candidate in row order (with the current world matrices), closed with the four
+ * bytes of the occluder count: the key of the backend's occlusion history.
+ * Computed on the device from the candidate inputs, no candidate rows needed;
+ * waits for the result. */
+int vkrhip_candidate_epoch(vkrhip_ctx *ctx, uint64_t *out_hash, uint32_t *out_occluders);
+
 /* ---- multi-GPU exchange planned on the device (no reference counterpart) ------
  * The per-frame exchange of one rank with the others without a host round trip:
  *   vkrhip_exchange_pack   -> this rank's block in `block_dev`

@@ -69,3 +69,58 @@ def test_encode_rows_and_commands(oracle):
     assert cmds["vertex_offset"][first: first + 2].tolist() == [-1, -4]
     assert (cmds["instance_count"][first: first + 2] == 1).all()
     assert cmds["index_count"][:8].tolist() == [0] * 8      # view 0 untouched
+
+
+# ---- candidate epoch (vkr_vk_candidate_epoch, vkr_vulkan_draws.c:9-44) ----------
+FNV_STANDARD_BASIS = 0xcbf29ce484222325
+# vkr_vulkan_draws.c:21 starts from 1469598103934665603, the standard basis
+# 14695981039346656037 without its last digit; parity means following the reference
+REFERENCE_BASIS = 1469598103934665603
+
+
+def _fnv1a64(data: bytes, h: int = FNV_STANDARD_BASIS) -> int:
+    for b in data:
+        h = ((h ^ b) * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
+def python_candidate_epoch(cand) -> int:
+    """The epoch hash stated a second time, in plain Python over the row bytes:
+    words 0-6 (mesh, geometry, submesh_index, material), 8-23 (instance.model),
+    28-31 (local_bounding_sphere), 32-33 (state_bucket, flags) of each 144-byte
+    row that has CAMERA_OPAQUE (0x2) in its flags, then the row count."""
+    rows = np.ascontiguousarray(cand).view(np.uint8).reshape(-1, 144)
+    h, occluders = REFERENCE_BASIS, 0
+    for row in rows:
+        flags = int(row[132:136].view(np.uint32)[0])
+        if not flags & 0x2:
+            continue
+        occluders += 1
+        h = _fnv1a64(row[0:28].tobytes() + row[32:96].tobytes() + row[112:136].tobytes(), h)
+    return _fnv1a64(int(occluders).to_bytes(4, "little"), h)
+
+
+def test_epoch_hash_known_answers(oracle):
+    from oracle import pyoracle as P
+    # published FNV-1a 64 vectors pin the byte step
+    assert _fnv1a64(b"") == 0xcbf29ce484222325
+    assert _fnv1a64(b"a") == 0xaf63dc4c8601ec8c
+    assert _fnv1a64(b"foobar") == 0x85944171f73967e8
+    # no candidates: only the four count bytes
+    assert oracle.candidate_epoch(np.zeros(0, P.CANDIDATE_DT)) == _fnv1a64(b"\0\0\0\0", REFERENCE_BASIS)
+    rng = np.random.default_rng(12)
+    c = np.zeros(37, P.CANDIDATE_DT)
+    raw = c.view(np.uint8).reshape(-1, 144)
+    raw[:] = rng.integers(0, 256, raw.shape, dtype=np.uint8)   # padding bytes included
+    c["flags"] = rng.integers(0, 8, 37)
+    assert 0 < int((c["flags"] & 2 != 0).sum()) < 37
+    assert oracle.candidate_epoch(c) == python_candidate_epoch(c)
+    # a field that is not hashed does not change it, a hashed one does
+    base = oracle.candidate_epoch(c)
+    d = c.copy()
+    d["object_id"] += 1
+    assert oracle.candidate_epoch(d) == base
+    first = int(np.flatnonzero(c["flags"] & 2)[0])
+    d = c.copy()
+    d["model"][first, 5] += np.float32(1.0)
+    assert oracle.candidate_epoch(d) != base

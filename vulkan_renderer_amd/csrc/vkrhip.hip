@@ -21,6 +21,7 @@
 #include "k_fused.hpp"
 #include "k_pack.hpp"
 #include "k_exchange.hpp"
+#include "k_epoch.hpp"
 #include "k_sort.hpp"
 #include "k_transform.hpp"
 
@@ -146,6 +147,10 @@ struct vkrhip_ctx {
   DevBuf<const uint64_t *> merge_ptrs;
   DevBuf<uint64_t> merge_lens;
   DevBuf<uint64_t> concat_desc;
+  // candidate epoch hash workspace
+  DevBuf<uint64_t> epoch_maps, epoch_maps_low, epoch_wave_maps, epoch_pairs, epoch_result;
+  DevBuf<uint8_t> epoch_enter_low, epoch_enter_high;
+  DevBuf<uint32_t> epoch_wave_occluders;
   // device-planned exchange
   DevBuf<uint64_t> exch_desc, exch_rank_view_start, exch_prefix, exch_runs;
 
@@ -438,6 +443,14 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->merge_lens);
   dev_free(c->concat_desc);
   dev_free(c->exch_desc);
+  dev_free(c->epoch_maps);
+  dev_free(c->epoch_maps_low);
+  dev_free(c->epoch_wave_maps);
+  dev_free(c->epoch_pairs);
+  dev_free(c->epoch_result);
+  dev_free(c->epoch_enter_low);
+  dev_free(c->epoch_enter_high);
+  dev_free(c->epoch_wave_occluders);
   dev_free(c->exch_rank_view_start);
   dev_free(c->exch_prefix);
   dev_free(c->exch_runs);
@@ -1427,6 +1440,55 @@ int vkrhip_merge_runs(vkrhip_ctx *c, uint32_t g, const uint64_t *const *runs_key
   hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, c->stream,
                      c->merge_ptrs.p, c->merge_lens.p, g, total, out_keys_dev);
   HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+int vkrhip_candidate_epoch(vkrhip_ctx *c, uint64_t *out_hash, uint32_t *out_occluders) {
+  if (!c || !out_hash) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  const uint64_t n = c->n_cand;
+  const uint64_t waves = ceil_div(n, 64);
+  TRY(dev_alloc(c, c->epoch_maps, std::max<uint64_t>(n, 1)));
+  TRY(dev_alloc(c, c->epoch_maps_low, std::max<uint64_t>(n, 1)));
+  TRY(dev_alloc(c, c->epoch_wave_maps, std::max<uint64_t>(waves, 1)));
+  TRY(dev_alloc(c, c->epoch_pairs, std::max<uint64_t>(waves, 1) * 2));
+  TRY(dev_alloc(c, c->epoch_result, 2));
+  TRY(dev_alloc(c, c->epoch_enter_low, std::max<uint64_t>(waves, 1)));
+  TRY(dev_alloc(c, c->epoch_enter_high, std::max<uint64_t>(waves, 1)));
+  TRY(dev_alloc(c, c->epoch_wave_occluders, std::max<uint64_t>(waves, 1)));
+  EpochArgs a{};
+  a.ident = c->ident.p;
+  a.world = c->world.p;
+  a.node = c->node_identity ? nullptr : c->node.p;
+  a.sphere = c->sphere.p;
+  a.cflags = c->cflags.p;
+  a.n = n;
+  a.waves = waves;
+  a.maps = c->epoch_maps.p;
+  a.maps_low = c->epoch_maps_low.p;
+  a.wave_maps = c->epoch_wave_maps.p;
+  a.enter_low = c->epoch_enter_low.p;
+  a.enter_high = c->epoch_enter_high.p;
+  a.wave_occluders = c->epoch_wave_occluders.p;
+  a.pairs = c->epoch_pairs.p;
+  a.result = c->epoch_result.p;
+  if (waves) {
+    const unsigned grid = (unsigned)ceil_div(waves * 64, 256);
+    hipLaunchKernelGGL(k_epoch_low, dim3(grid), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_epoch_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, a.wave_maps, waves,
+                       (uint32_t)(FNV_OFFSET & 0xfu), a.enter_low);
+    hipLaunchKernelGGL(k_epoch_high, dim3(grid), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_epoch_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, a.wave_maps, waves,
+                       (uint32_t)((FNV_OFFSET >> 4) & 0xfu), a.enter_high);
+    hipLaunchKernelGGL(k_epoch_affine, dim3(grid), dim3(256), 0, c->stream, a);
+  }
+  hipLaunchKernelGGL(k_epoch_final, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  uint64_t host[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(host, c->epoch_result.p, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *out_hash = host[0];
+  if (out_occluders) *out_occluders = (uint32_t)host[1];
   return VKRHIP_OK;
 }
 

@@ -367,6 +367,14 @@ class HipScene:
                                                desc.shape[0]))
 
 
+    def candidate_epoch(self):
+        """(hash, occluder_count) of vkr_vk_candidate_epoch
+        (lib/src/renderer/vulkan/vkr_vulkan_draws.c:19-44) for the current candidates
+        and world matrices, computed on the device."""
+        h, k = C.c_uint64(0), C.c_uint32(0)
+        self._ok(self.lib.vkrhip_candidate_epoch(self.ctx, C.byref(h), C.byref(k)))
+        return int(h.value), int(k.value)
+
     # ---- multi-GPU exchange planned on the device --------------------------
     def exchange_block_words(self, views: int, vis_cap: int, key_cap: int) -> int:
         return int(self.lib.vkrhip_exchange_block_words(views, vis_cap, key_cap))
