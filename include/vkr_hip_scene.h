@@ -359,6 +359,21 @@ void vkrhip_build_view_set(const float *view, const float *projection,
 uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
                          uint32_t *new_parent, uint64_t *level_offsets);
 
+/* scene_entity_is_visible (vkr_scene_system.c:1935-1977) for every node of a
+ * hierarchy stored parents-first (the order vkrhip_levelize produces): walking up
+ * from a node, the first SceneVisibility with visible == 0 hides it, the first
+ * one with inherit_parent == 0 ends the walk as visible, nodes without the
+ * component pass the question to their parent, the top of the chain is visible.
+ * spec[i]: bit 0 = the node has a SceneVisibility, bit 1 = visible, bit 2 =
+ * inherit_parent. out_visible[i] = 0/1. Host side, like the reference (its
+ * result decides which rows application_build_world_payload enumerates,
+ * application.h:688,734,772-774, i.e. the numbering of source rows: the
+ * caller re-runs vkrhip_set_candidates with the rows of the visible nodes
+ * after vkr_scene_set_visibility, which the reference answers with a full
+ * render-bridge sync as well, vkr_scene_system.c:1634-1655). */
+void vkrhip_effective_visibility(const uint32_t *parent, const uint8_t *spec, uint64_t n,
+                                 uint8_t *out_visible);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,6 +191,8 @@ class Oracle:
             f32p, vp, f32p, u32p, u32p, C.c_uint64, f32p, u32p, C.c_uint32, C.c_uint32,
             C.c_uint64, C.c_uint64, C.c_float, vp, vp, vp, vp]
         L.vko_encode_visible_rows.argtypes = [vp, u32p, vp, vp]
+        L.vko_entity_is_visible.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
+        L.vko_entity_is_visible.restype = C.c_int
         L.vko_candidate_epoch.argtypes = [vp, C.c_uint32]
         L.vko_candidate_epoch.restype = C.c_uint64
         L.vko_merge_runs_desc.argtypes = [vp, u64p, C.c_uint32, u64p]
@@ -421,6 +423,14 @@ class Oracle:
             C.c_void_p(rows.ctypes.data), C.c_void_p(vis.ctypes.data), C.c_void_p(st.ctypes.data),
             C.c_uint32(view), C.c_uint32(partition_capacity), C.c_void_p(out.ctypes.data))
         return out
+
+    def entity_is_visible(self, parent, spec):
+        """vko_entity_is_visible for every node."""
+        parent = np.ascontiguousarray(parent, dtype=np.uint32)
+        spec = np.ascontiguousarray(spec, dtype=np.uint8)
+        n = parent.shape[0]
+        return np.array([self.lib.vko_entity_is_visible(parent.ctypes.data, spec.ctypes.data, n, i)
+                         for i in range(n)], np.uint8)
 
     def candidate_epoch(self, candidates):
         c = np.ascontiguousarray(candidates)

@@ -865,6 +865,27 @@ void vko_encode_visible_rows(const vko_gpu_candidate_row *rows, const uint32_t *
   }
 }
 
+/* vkr_scene_system.c:1935-1977 */
+int vko_entity_is_visible(const uint32_t *parent, const uint8_t *spec, uint64_t n, uint64_t node) {
+  uint64_t depth = 0;
+  uint64_t current = node;
+  while (current < n && depth < n) { /* max_depth = directory capacity */
+    const uint8_t sp = spec[current];
+    if (sp & 1u) {
+      if (!(sp & 2u))
+        return 0;
+      if (!(sp & 4u))
+        return 1;
+    }
+    const uint32_t p = parent[current];
+    if (p == VKO_NO_PARENT)
+      break;
+    current = p;
+    depth++;
+  }
+  return 1;
+}
+
 /* vkr_vulkan_draws.c:9-44 */
 static uint64_t vko_hash_bytes(uint64_t hash, const void *bytes, uint64_t size) {
   const uint8_t *data = bytes;

@@ -341,6 +341,11 @@ void vko_encode_commands(const vko_gpu_candidate_row *rows, const uint32_t *visi
 void vko_encode_visible_rows(const vko_gpu_candidate_row *rows, const uint32_t *visible,
                              const vko_compaction_state *state, vko_gpu_visible_row *out);
 
+/* scene_entity_is_visible (vkr_scene_system.c:1935-1977): the walk up the parent
+ * chain from `node`, for a hierarchy in any numbering. spec[i]: bit 0 = has a
+ * SceneVisibility, bit 1 = visible, bit 2 = inherit_parent. */
+int vko_entity_is_visible(const uint32_t *parent, const uint8_t *spec, uint64_t n, uint64_t node);
+
 /* Backend pack epoch hash (vkr_vulkan_draws.c:9-44). */
 uint64_t vko_candidate_epoch(const vko_world_candidate *candidates, uint32_t count);
 

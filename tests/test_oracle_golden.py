@@ -226,3 +226,31 @@ def test_kat_parent_child(oracle, kats):
                                          flags=np.full(2, 0x01, np.uint8))
     assert np.abs(world[1] - np.array(k["expected_world"], np.float32)).max() < k["tolerance"]
     assert_bits_equal(world[1], np.array(k["expected_world"], np.float32), "child world")
+
+
+def test_effective_visibility_equals_the_parent_chain_walk(oracle):
+    """The library's parents-first pass (vkrhip_effective_visibility) against the
+    oracle's literal walk of scene_entity_is_visible, on random hierarchies with
+    every combination of {no component, hidden, visible+inherit, visible+own}."""
+    from vulkan_renderer_amd import effective_visibility, levelize, synth
+    rng = np.random.default_rng(77)
+    for n, depth in ((1, 1), (50, 3), (4000, 6), (4000, 12)):
+        sizes = synth.level_sizes(n, depth, fanout=3, roots=2)
+        parent, _ = synth.build_parents(sizes)
+        n = parent.shape[0]
+        spec = rng.choice(np.array([0, 1, 3, 5, 7, 2, 6], np.uint8), n,
+                          p=[0.4, 0.05, 0.1, 0.05, 0.3, 0.05, 0.05])
+        got = effective_visibility(parent, spec)
+        assert (got == oracle.entity_is_visible(parent, spec)).all()
+        assert 0 < got.sum() < n or n == 1
+        # the same in a shuffled numbering, brought parents-first by levelize
+        perm = rng.permutation(n).astype(np.uint32)
+        inv = np.empty(n, np.uint32)
+        inv[perm] = np.arange(n, dtype=np.uint32)
+        parent_s = np.where(parent[perm] == 0xFFFFFFFF, 0xFFFFFFFF, inv[np.minimum(parent[perm], n - 1)]).astype(np.uint32)
+        spec_s = spec[perm]
+        expect_s = oracle.entity_is_visible(parent_s, spec_s)
+        order, new_parent, _ = levelize(parent_s)
+        got_s = np.empty(n, np.uint8)
+        got_s[order] = effective_visibility(new_parent, spec_s[order])
+        assert (got_s == expect_s).all()

@@ -7,8 +7,9 @@ include/vkr_hip_scene.h (libvkrhip.so, built in-tree by vulkan_renderer_amd.buil
 from . import _native  # noqa: F401
 from .scene import (CANDIDATE_DT, DRAW_DT, INSTANCE_DT, FrameResult, HipScene, ViewState,  # noqa: F401
                     build_view_set, frustum_from_matrix, frustum_from_view_projection, levelize,
+                    effective_visibility,
                     mat4_mul)
 
 __all__ = ["HipScene", "FrameResult", "ViewState", "build_view_set", "frustum_from_matrix",
-           "frustum_from_view_projection", "levelize", "mat4_mul", "DRAW_DT", "INSTANCE_DT",
+           "frustum_from_view_projection", "levelize", "effective_visibility", "mat4_mul", "DRAW_DT", "INSTANCE_DT",
            "CANDIDATE_DT"]

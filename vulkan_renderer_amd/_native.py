@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_exchange_block_words", "vkrhip_exchange_result_words", "vkrhip_exchange_pack",
     "vkrhip_exchange_merge", "vkrhip_candidate_epoch",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
-    "vkrhip_levelize",
+    "vkrhip_levelize", "vkrhip_effective_visibility",
 ]
 
 
@@ -196,6 +196,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_build_view_set.restype = None
     L.vkrhip_levelize.argtypes = [vp, u64, vp, vp, vp]
     L.vkrhip_levelize.restype = u32
+    L.vkrhip_effective_visibility.argtypes = [vp, vp, u64, vp]
+    L.vkrhip_effective_visibility.restype = None
     _lib = L
     return L
 

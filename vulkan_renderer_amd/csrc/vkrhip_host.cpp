@@ -97,6 +97,19 @@ void vkrhip_build_view_set(const float *view, const float *projection,
   }
 }
 
+void vkrhip_effective_visibility(const uint32_t *parent, const uint8_t *spec, uint64_t n,
+                                 uint8_t *out_visible) {
+  // parents come first, so the answer of the parent is already there
+  for (uint64_t i = 0; i < n; ++i) {
+    const bool top = parent[i] == VKRHIP_NO_PARENT || parent[i] >= i;
+    const uint8_t above = top ? (uint8_t)1 : out_visible[parent[i]];
+    const uint8_t sp = spec[i];
+    uint8_t v = above;
+    if (sp & 1u) v = !(sp & 2u) ? (uint8_t)0 : ((sp & 4u) ? above : (uint8_t)1);
+    out_visible[i] = v;
+  }
+}
+
 uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
                          uint32_t *new_parent, uint64_t *level_offsets) {
   if (n == 0) return 0;

@@ -451,3 +451,15 @@ def levelize(parent):
     if n and not levels:
         raise MemoryError("vkrhip_levelize failed")
     return order, new_parent, offsets[: levels + 1].copy()
+
+
+def effective_visibility(parent, spec) -> np.ndarray:
+    """scene_entity_is_visible (lib/src/renderer/systems/vkr_scene_system.c:1935-1977)
+    for every node of a parents-first hierarchy. spec: bit 0 has a SceneVisibility,
+    bit 1 visible, bit 2 inherit_parent. Returns 0/1 bytes."""
+    lib = N.load()
+    parent = N.as_u32(parent)
+    spec = np.ascontiguousarray(spec, dtype=np.uint8)
+    out = np.empty(parent.shape[0], np.uint8)
+    lib.vkrhip_effective_visibility(N.ptr(parent), N.ptr(spec), parent.shape[0], N.ptr(out))
+    return out
