@@ -148,6 +148,9 @@ typedef struct vkrhip_device_outputs {
                                          per visible slot when STAGE_ENCODE ran */
   const void *commands;               /* (view*4+bucket)*partition_capacity + local: 20-byte
                                          indirect commands; null when partition_capacity is 0 */
+  const void *transmission_gpu_candidates; /* transmission_gpu_candidate_count rows (144 B): the
+                                         rows of the transmissive sources once more, in source
+                                         order (application.h:643-645); null when there are none */
 } vkrhip_device_outputs;
 
 /* Backend publication state, flattened (VkrVulkanPublishedGeometry,
@@ -257,6 +260,9 @@ int vkrhip_read_transparent_visible(vkrhip_ctx *ctx, uint64_t first, uint64_t co
 int vkrhip_read_transparent(vkrhip_ctx *ctx, uint64_t count, void *draws48, void *instances80,
                             uint64_t *keys, uint32_t *source);
 int vkrhip_read_candidates(vkrhip_ctx *ctx, uint64_t first, uint64_t count, void *rows144);
+/* rows of VkrWorldPassPayload.transmission_gpu_candidates (vkr_render_packet.h:162-179) */
+int vkrhip_read_transmission_candidates(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
+                                        void *rows144);
 int vkrhip_read_packed(vkrhip_ctx *ctx, uint64_t count, void *rows48, void *instances80);
 int vkrhip_read_visible_rows(vkrhip_ctx *ctx, uint32_t view, uint64_t count, void *rows32);
 /* `count` commands of (view, bucket), starting at local index 0 */

@@ -42,9 +42,15 @@ def test_deep_hierarchy_five_views(oracle):
     ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, tie_eps=1e-5)
     with hip_scene_for(sc, 5, tie_epsilon=1e-5) as hs:
         hs.set_views(planes, required, vs.view)
-        hs.frame()
+        hs.frame(STAGE_TRANSFORM | STAGE_CULL | STAGE_TRANSPARENT | STAGE_CANDIDATES)
         info = compare_frame(hs, ref, sc)
         assert sum(v.visible_count for v in info.views) > 1000
+        # both candidate streams (application.h:641-645)
+        assert hs.read_candidates().tobytes() == ref["payload"]["gpu_candidates"].tobytes()
+        expect = ref["payload"]["transmission_candidates"]
+        assert 1000 < expect.shape[0] == info.transmission_gpu_candidate_count
+        got = hs.read_transmission_candidates(info.transmission_gpu_candidate_count)
+        assert got.tobytes() == expect.tobytes(), "transmission_gpu_candidates rows"
 
 
 def test_sixty_four_views(oracle):

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_read_packed", "vkrhip_read_visible_rows", "vkrhip_read_commands", "vkrhip_set_profiling",
     "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_exchange_block_words", "vkrhip_exchange_result_words", "vkrhip_exchange_pack",
-    "vkrhip_exchange_merge", "vkrhip_candidate_epoch",
+    "vkrhip_exchange_merge", "vkrhip_candidate_epoch", "vkrhip_read_transmission_candidates",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize", "vkrhip_effective_visibility",
 ]
@@ -119,6 +119,7 @@ class DeviceOutputs(C.Structure):
         ("packed_instances", C.c_void_p),
         ("visible_rows", C.c_void_p),
         ("commands", C.c_void_p),
+        ("transmission_gpu_candidates", C.c_void_p),
     ]
 
 
@@ -180,6 +181,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_merge_runs.argtypes = [vp, u32, vp, vp, vp]
     L.vkrhip_concat_ranges.argtypes = [vp, vp, vp, vp, u32]
     L.vkrhip_candidate_epoch.argtypes = [vp, vp, vp]
+    L.vkrhip_read_transmission_candidates.argtypes = [vp, u64, u64, vp]
     L.vkrhip_exchange_block_words.argtypes = [u32, u32, u32]
     L.vkrhip_exchange_block_words.restype = u64
     L.vkrhip_exchange_result_words.argtypes = [u32]

@@ -503,15 +503,19 @@ struct CandidateEmitArgs {
   const uint32_t *cflags;
   uint4 *rows;  // 9 x uint4 per candidate: VkrWorldDrawCandidate (144 B)
   uint64_t n;
+  const uint32_t *list;  // null: output row r is source row r; else source row list[r]
 };
 
 // application_emit_world_source, application.h:617-641: one 144-byte
 // VkrWorldDrawCandidate per source row, written as nine 16-byte pieces by nine
 // of every sixteen lanes.
 __global__ __launch_bounds__(256) void k_emit_candidates(CandidateEmitArgs a) {
-  const uint64_t row = (uint64_t)blockIdx.x * 16u + (threadIdx.x >> 4);
+  const uint64_t out_row = (uint64_t)blockIdx.x * 16u + (threadIdx.x >> 4);
   const uint32_t piece = threadIdx.x & 15u;
-  if (row >= a.n || piece >= 9u) return;
+  if (out_row >= a.n || piece >= 9u) return;
+  // the transmission stream repeats the rows of the transmissive sources
+  // (application.h:643-645)
+  const uint64_t row = a.list ? a.list[out_row] : out_row;
   const uint4 id0 = a.ident[row * 2u];
   const uint4 id1 = a.ident[row * 2u + 1u];
   uint4 o;
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256) void k_emit_candidates(CandidateEmitArgs a) {
     const uint32_t cf = a.cflags[row];
     o = make_uint4((cf >> CF_BUCKET_SHIFT) & 0xfu, cf & CF_REF_MASK, 0u, 0u);
   }
-  a.rows[row * 9u + piece] = o;
+  a.rows[out_row * 9u + piece] = o;
 }
 
 }  // namespace vkr

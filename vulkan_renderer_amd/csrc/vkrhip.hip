@@ -115,6 +115,9 @@ struct vkrhip_ctx {
   uint64_t visible_stride = 0;
   DevBuf<float4> world_bounds;
   DevBuf<uint4> cand_rows;
+  DevBuf<uint32_t> transmission_list;  // source rows with a transmissive material, ascending
+  uint64_t n_transmission = 0;
+  DevBuf<uint4> transmission_rows;
 
   // backend pack / encode (allocated when a publication is set / the stage first runs)
   bool published = false;
@@ -443,6 +446,8 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->merge_lens);
   dev_free(c->concat_desc);
   dev_free(c->exch_desc);
+  dev_free(c->transmission_list);
+  dev_free(c->transmission_rows);
   dev_free(c->epoch_maps);
   dev_free(c->epoch_maps_low);
   dev_free(c->epoch_wave_maps);
@@ -607,9 +612,18 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
   }
   TRY(bind_device(c));
   uint64_t blend = 0;
+  std::vector<uint32_t> transmissive;
   for (uint64_t i = 0; i < n; ++i) {
     const uint32_t m = matbits[i];
     if ((m & VKRHIP_MAT_ALPHA_MASK) == 2u && !(m & VKRHIP_MAT_TRANSMISSIVE)) blend++;
+    if (m & VKRHIP_MAT_TRANSMISSIVE) transmissive.push_back((uint32_t)i);
+  }
+  c->n_transmission = transmissive.size();
+  if (!transmissive.empty()) {
+    TRY(dev_alloc(c, c->transmission_list, transmissive.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->transmission_list.p, transmissive.data(), transmissive.size() * 4,
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vector goes out of scope
   }
   c->n_cand = n;
   c->node_identity = node == nullptr;
@@ -1101,6 +1115,14 @@ static int launch_candidates(vkrhip_ctx *c) {
   a.n = c->n_cand;
   hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand, 16)), dim3(256), 0,
                      c->stream, a);
+  if (c->n_transmission) {
+    TRY(dev_alloc(c, c->transmission_rows, c->n_transmission * 9));
+    a.rows = c->transmission_rows.p;
+    a.n = c->n_transmission;
+    a.list = c->transmission_list.p;
+    hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_transmission, 16)), dim3(256),
+                       0, c->stream, a);
+  }
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
@@ -1214,6 +1236,7 @@ int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   out->transparent_keys = c->out_keys.p;
   out->transparent_source = c->out_source.p;
   out->gpu_candidates = c->cand_rows.p;
+  out->transmission_gpu_candidates = c->n_transmission ? c->transmission_rows.p : nullptr;
   out->world_bounds = reinterpret_cast<const float *>(c->world_bounds.p);
   out->device_counts = c->counters();
   out->packed_rows = c->packed_rows.p;
@@ -1281,6 +1304,15 @@ int vkrhip_read_candidates(vkrhip_ctx *c, uint64_t first, uint64_t count, void *
   if (!c->cand_rows.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_CANDIDATES has not run");
   TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_candidates"));
   return read_back(c, rows144, c->cand_rows.p + first * 9, count * 144);
+}
+
+int vkrhip_read_transmission_candidates(vkrhip_ctx *c, uint64_t first, uint64_t count,
+                                        void *rows144) {
+  if (!c || !rows144) return VKRHIP_ERR_ARG;
+  if (!c->cand_rows.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_CANDIDATES has not run");
+  TRY(check_range(c, first, count, c->n_transmission, "read_transmission_candidates"));
+  if (count == 0) return VKRHIP_OK;
+  return read_back(c, rows144, c->transmission_rows.p + first * 9, count * 144);
 }
 
 int vkrhip_read_packed(vkrhip_ctx *c, uint64_t count, void *rows48, void *instances80) {

@@ -304,6 +304,12 @@ class HipScene:
         self._ok(self.lib.vkrhip_read_candidates(self.ctx, 0, self.n_candidates, N.ptr(out)))
         return out
 
+    def read_transmission_candidates(self, count: int) -> np.ndarray:
+        out = np.zeros(count, CANDIDATE_DT)
+        if count:
+            self._ok(self.lib.vkrhip_read_transmission_candidates(self.ctx, 0, count, N.ptr(out)))
+        return out
+
     def read_packed(self, count: int):
         rows = np.zeros(count, GPU_ROW_DT)
         inst = np.zeros(count, INSTANCE_DT)
