@@ -631,6 +631,7 @@ struct GatherArgs {
 };
 
 constexpr int GATHER_BLOCK = 256;  // four waves, one segment each
+constexpr int GATHER_UNROLL = 4;
 
 __host__ __device__ inline size_t gather_shared_bytes(uint32_t views) {
   return sizeof(uint32_t) * 3u * (size_t)(views * 4u + 1u) * (GATHER_BLOCK / 64);
@@ -706,18 +707,35 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
   t_count = (uint32_t)__shfl((int)t_count, (int)(vrows & 63u), 64);
   t_offset = (uint32_t)__shfl((int)t_offset, (int)(vrows & 63u), 64);
 
-  // flat copy: entry e belongs to the last row whose first entry is <= e
-  for (uint32_t e = lane; e < flat; e += 64u) {
-    uint32_t lo = 0u, hi = vrows;  // rows [lo, hi) still possible; e_start is non-decreasing
-    while (hi - lo > 1u) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (e_start[mid] <= e) lo = mid; else hi = mid;
+  // flat copy: entry e belongs to the last row whose first entry is <= e. Four
+  // entries per lane and step, so that four staging reads are in flight before
+  // the first store needs its value.
+  for (uint32_t e0 = lane; e0 < flat; e0 += 64u * GATHER_UNROLL) {
+    uint32_t idx[GATHER_UNROLL];
+    uint64_t out[GATHER_UNROLL];
+#pragma unroll
+    for (int u = 0; u < GATHER_UNROLL; ++u) {
+      const uint32_t e = min(e0 + 64u * (uint32_t)u, flat - 1u);  // clamped: the load is unconditional
+      uint32_t lo = 0u, hi = vrows;  // rows [lo, hi) still possible; e_start is non-decreasing
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (e_start[mid] <= e) lo = mid; else hi = mid;
+      }
+      const uint32_t k = e - e_start[lo];
+      const uint32_t v = lo >> 2;
+      idx[u] = a.stage[(uint64_t)v * a.stage_stride + e_src[lo] + k];
+      out[u] = (uint64_t)v * a.visible_stride + e_dst[lo] + k;
     }
-    const uint32_t k = e - e_start[lo];
-    const uint32_t v = lo >> 2;
-    const uint32_t idx = a.stage[(uint64_t)v * a.stage_stride + e_src[lo] + k];
-    a.visible[(uint64_t)v * a.visible_stride + e_dst[lo] + k] =
-        a.remap ? a.remap[idx] : (uint32_t)(a.index_base + idx);
+    if (a.remap) {
+#pragma unroll
+      for (int u = 0; u < GATHER_UNROLL; ++u) idx[u] = a.remap[idx[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < GATHER_UNROLL; ++u) idx[u] = (uint32_t)(a.index_base + idx[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < GATHER_UNROLL; ++u)
+      if (e0 + 64u * (uint32_t)u < flat) a.visible[out[u]] = idx[u];
   }
   for (uint32_t k = lane; k < t_count; k += 64u) {
     const uint64_t pos = (uint64_t)t_offset + k;
