@@ -96,9 +96,8 @@ struct SortArgs {
   uint32_t shift;
 };
 
-// LDS of the single-workgroup sort.
+// LDS of the single-workgroup sort (the keys stay in global memory).
 struct SmallSortShared {
-  uint64_t keys[2][SMALL_KEYS];
   uint16_t rank[SMALL_KEYS];  // rank of each key of the current tile inside its wave's digit run
   uint32_t whist[SMALL_WAVES][SORT_RADIX];
   uint32_t base[SORT_RADIX];
@@ -109,8 +108,7 @@ struct SmallSortShared {
 // One stable pass of a whole array by ONE workgroup: digit histogram ->
 // exclusive scan -> tiles of SMALL_KEYS keys in order, each ranked by wave_rank
 // and scattered at (running digit base + wave prefix + rank). Returns false
-// (and writes nothing) when every key has the same digit. src/dst may be LDS or
-// global memory.
+// (and writes nothing) when every key has the same digit.
 __device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *dst,
                                                  uint32_t count, uint32_t shift,
                                                  SmallSortShared &s) {
@@ -400,8 +398,8 @@ __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
 // keys greater than it. A block takes RANK_BLOCK_KEYS keys; its eight waves
 // split the key array between them and sweep their stretch past the block's
 // keys, 64 keys per load, one compare + ballot population count per (key,
-// load); the partial counts meet in LDS and two waves write the eight 16-byte
-// pieces of the sixteen rows. The sweep reads the array straight from L2 (every
+// load); the partial counts meet in LDS and one wave writes the eight 16-byte
+// pieces of the eight rows. The sweep reads the array straight from L2 (every
 // wave load is 512 consecutive bytes) - no copy of the whole array per block, no
 // barrier before the sweep. count^2 / 64 compares: 1M wave-steps at 8192 keys,
 // spread over every CU, against four passes of barriers and LDS atomics on one
@@ -411,7 +409,7 @@ __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
 // by streaming radix passes through global memory and emits every row. That
 // only happens when the host launched this kernel on a stale small estimate of
 // the count; it is correct, but runs at one CU's bandwidth.
-constexpr int RANK_BLOCK_KEYS = 16;
+constexpr int RANK_BLOCK_KEYS = 8;
 constexpr int RANK_LOADS = 4;  // sweep loads in flight per wave
 constexpr uint32_t RANK_LIMIT = SMALL_KEYS;
 
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_
       mine[k] = block_keys[min(g * RANK_BLOCK_KEYS + (uint32_t)k, count - 1u)];
       greater[k] = 0u;
     }
-    // waves 0 and 1 emit: lane = 8 * row slot + piece; the piece is gathered
+    // wave 0 emits (a wave per eight keys): lane = 8 * row slot + piece; the piece is gathered
     // while the sweep works out where the row goes
     const uint32_t slot = wave * 8u + (lane >> 3);
     uint64_t own_key = 0ull;
