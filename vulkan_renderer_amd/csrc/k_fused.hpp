@@ -77,6 +77,7 @@ struct FusedHead {
   uint32_t raw[4];  // node flag bytes as loaded (sub-round mapping)
   uint32_t fp;      // after fused_resolve_head: the four pass-1 flag bytes packed (byte r =
                     // sub-round r), 0 outside the level
+  uint32_t rebuild; // after fused_issue_body: bit r = sub-round r rebuilds its local matrix from TRS
   uint32_t p;       // parent of node (round base + thread)
   float4 ls;        // local sphere of candidate (round base + thread)
   uint32_t cf;
@@ -126,48 +127,59 @@ __device__ __forceinline__ void fused_resolve_head(const FusedArgs &a, uint64_t 
 }
 
 struct FusedBody {
-  float4 m[4];  // per sub-round: the local column when the node is dirty, else the stored world column
+  // per sub-round: the local column when the node is dirty, the stored world
+  // column when it is clean, and one piece of the node's TRS when the local
+  // matrix has to be rebuilt (lane 0 position, 1 rotation, 2 scale)
+  float4 m[4];
 };
 
-// Needs a resolved head. The node's own flags pick the matrix to fetch: dirty ->
-// the local column; clean -> the stored world column (the cull phase needs it
+// Needs a resolved head. The node's own flags pick what to fetch: dirty -> the
+// local column; clean -> the stored world column (the cull phase needs it
 // unless the parent turns out to have moved, which is handled when the round is
-// computed).
+// computed); TRS changed (pass 1, vkr_scene_system.c:598-602) -> the four lanes
+// of the node fetch position, rotation and scale, one 16-byte piece each, and
+// the local matrix is rebuilt from them when the round is computed. Either way
+// it is one unconditional load per sub-round.
 __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h, FusedBody &b) {
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
+  const bool have_trs = a.t.pos != nullptr;
+  const float4 *piece = col == 1u ? a.t.quat : (col == 2u ? a.t.scale : a.t.pos);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const uint64_t node = tile_base + clamp_rel(rbase + sub_slot(r), lo, hi);
     const uint32_t f = h.f(r);
     const bool hl = (f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
-    const float4 *src = hl ? a.t.local : a.t.world;
-    // a local that is about to be rebuilt from TRS is not fetched: those lanes
-    // all read one fixed element instead (a single cached request), which keeps
-    // the load unconditional
-    const bool rebuilt = a.t.pos != nullptr && (f & F_DIRTY_LOCAL) != 0;
-    b.m[r] = src[rebuilt ? a.t.begin * 4u : node * 4u + col];
-  }
-  // pass 1, vkr_scene_system.c:598-602: a changed TRS rebuilds the local matrix
-  if (a.t.pos != nullptr) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (h.f(r) & F_DIRTY_LOCAL) {
-        const uint64_t node = tile_base + rbase + sub_slot(r);
-        b.m[r] = local_col_from_trs(a.t.pos[node], a.t.quat[node], a.t.scale[node], col);
-        a.t.local[node * 4u + col] = b.m[r];
-      }
-    }
+    const bool rebuilt = have_trs && (f & F_DIRTY_LOCAL) != 0;
+    const float4 *src = rebuilt ? piece + node : (hl ? a.t.local : a.t.world) + node * 4u + col;
+    b.m[r] = *src;
   }
   // DIRTY_LOCAL becomes DIRTY_WORLD (all four bytes at once); from here on a set
-  // DIRTY_WORLD bit also says that b.m holds the local column
-  h.fp = (h.fp | ((h.fp & 0x01010101u * F_DIRTY_LOCAL) << 1)) & ~(0x01010101u * F_DIRTY_LOCAL);
+  // DIRTY_WORLD bit also says that b.m holds the local column or, where
+  // h.rebuild says so, the piece it is rebuilt from
+  const uint32_t dl = h.fp & (0x01010101u * F_DIRTY_LOCAL);
+  h.rebuild = have_trs ? ((dl | (dl >> 7) | (dl >> 14) | (dl >> 21)) & 0xfu) : 0u;
+  h.fp = (h.fp | (dl << 1)) & ~(0x01010101u * F_DIRTY_LOCAL);
+}
+
+// The local column of a node whose four lanes hold position, rotation and scale
+// (lanes 0, 1, 2 of the quad): scene_compute_local_matrix,
+// vkr_scene_system.c:555-561.
+__device__ __forceinline__ float4 local_col_from_quad(float4 piece, uint32_t col) {
+  const float4 pos = quad_bcast4<0>(piece);
+  const float4 quat = quad_bcast4<1>(piece);
+  const float4 scale = quad_bcast4<2>(piece);
+  return local_col_from_trs(pos, quat, scale, col);
 }
 
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT>
-__global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a) {
+// Four waves per SIMD: a level of 1M nodes is exactly one resident set of blocks
+// (4 per CU), and the register budget of 128 lets the compiler keep the three
+// pipeline stages apart.
+__global__ __launch_bounds__(FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ uint32_t s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
@@ -252,6 +264,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void k_propagate_classify(FusedArgs a)
       const bool valid = rbase + slot >= lo && rbase + slot < hi;
       uint32_t fr = hd.f(r);
       float4 lcol = cur.m[r];
+      if (hd.rebuild & (1u << r)) {  // the same for the four lanes of the node
+        lcol = local_col_from_quad(lcol, col);
+        if (valid) a.t.local[node * 4u + col] = lcol;
+      }
       const uint32_t pf = HAS_PARENT ? (pfp >> (8 * r)) & 0xffu : 0u;
       // deferred dirty propagation, vkr_scene_system.c:1310-1316
       if (HAS_PARENT && valid && (pf & F_WORLD_UPDATED) && !(fr & F_DIRTY_WORLD)) {
