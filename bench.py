@@ -157,7 +157,7 @@ def main() -> int:
 
     from vulkan_renderer_amd import HipScene, build_view_set, frustum_from_matrix
     from vulkan_renderer_amd import _native as N
-    from vulkan_renderer_amd.parallel import ShardExchange
+    from vulkan_renderer_amd.parallel import RcclExchange, ShardExchange
 
     workload = dict(WORKLOADS[args.workload])
     if args.instances:
@@ -183,7 +183,11 @@ def main() -> int:
     hs.set_views(planes, required, vs.view)
     hs.frame(N.STAGE_TRANSFORM)  # materialise local matrices from TRS once (not timed)
     hs.sync()
-    exchange = ShardExchange(hs, world, rank, views) if (world > 1 or args.exchange) else None
+    exchange = None
+    if world > 1 or args.exchange:
+        # the library's own RCCL exchange; the torch collective only for the gloo rehearsal
+        exchange = (ShardExchange(hs, world, rank, views) if args.backend == "gloo" and world > 1
+                    else RcclExchange(hs, world, rank, views))
 
     dirty_bits = N.DIRTY_LOCAL if args.dirty == "local" else N.DIRTY_WORLD
 
@@ -276,7 +280,7 @@ def main() -> int:
             "moved_per_frame": "every node: " + ("TRS (locals rebuilt)" if args.dirty == "local"
                                                  else "world matrices re-propagated from cached locals"),
             "exchange": ("one all-gather of packed blocks (visible lists + draw-key runs), "
-                         "device-planned merge") if exchange is not None else "none",
+                         "device-planned merge, overlapped with the next frame") if exchange is not None else "none",
         },
         "roofline": roofline,
         "stage_us_warmup": stage_us,

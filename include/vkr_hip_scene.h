@@ -319,7 +319,7 @@ int vkrhip_candidate_epoch(vkrhip_ctx *ctx, uint64_t *out_hash, uint32_t *out_oc
  *   vkrhip_exchange_pack   -> this rank's block in `block_dev`
  *   (all-gather of the blocks with the caller's collective library, e.g. RCCL)
  *   vkrhip_exchange_merge  -> merged visible lists, merged draw keys, result words
- * All launches go to the context's stream and return at once.
+ * All launches return at once; pack goes to the context's stream.
  *
  * Block, in 32-bit words (vkrhip_exchange_block_words gives the total, a
  * multiple of 4): execution_ranges[view][bucket] = {offset, count} for every
@@ -339,9 +339,13 @@ int vkrhip_candidate_epoch(vkrhip_ctx *ctx, uint64_t *out_hash, uint32_t *out_oc
 uint64_t vkrhip_exchange_block_words(uint32_t views, uint32_t vis_cap, uint32_t key_cap);
 uint64_t vkrhip_exchange_result_words(uint32_t views);
 int vkrhip_exchange_pack(vkrhip_ctx *ctx, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap);
+/* hip_stream: the hipStream_t the merge is enqueued on; NULL = the context's
+ * stream. A caller that runs collective and merge on a stream of their own lets
+ * the next frame start right after vkrhip_exchange_pack. Merges of one context
+ * must not overlap each other (they share the planning tables). */
 int vkrhip_exchange_merge(vkrhip_ctx *ctx, const uint32_t *gathered_dev, uint32_t world,
                           uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
-                          uint64_t *merged_keys_dev, uint64_t *result_dev);
+                          uint64_t *merged_keys_dev, uint64_t *result_dev, void *hip_stream);
 
 /* ---- host-side mirrors of reference leaf functions (exact op order) -------- */
 /* vkr_frustum_from_matrix, lib/src/math/vkr_frustum.c:44-66 */
@@ -364,6 +368,29 @@ void vkrhip_build_view_set(const float *view, const float *projection,
  * (levels <= n). */
 uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
                          uint32_t *new_parent, uint64_t *level_offsets);
+
+/* ---- the whole exchange inside the library, over RCCL (no reference
+ * counterpart). One communicator per context; RCCL is bound at run time.
+ *   rank 0:  vkrhip_comm_unique_id(id)      -> send the 128 bytes to every rank
+ *   all:     vkrhip_comm_init(ctx, id, world, rank)          (collective)
+ *            vkrhip_exchange_configure(ctx, world, vis_cap, key_cap)
+ *   per frame, after vkrhip_frame:  vkrhip_exchange_run(ctx)
+ *   when the merged result is needed: vkrhip_exchange_finish(ctx, ...)
+ * vkrhip_exchange_run enqueues the pack on the context's stream and the
+ * all-gather and the merge on a second stream, into one of two buffer sets: the
+ * next vkrhip_frame may be enqueued at once and overlaps them. Without a
+ * communicator (world 1) the all-gather is a device copy. vkrhip_exchange_finish
+ * waits for the latest run and copies its result words (layout above,
+ * vkrhip_exchange_result_words(views) of them); when result[0] has flag 1 or 2 a
+ * rank did not fit: every rank sees the same flags and sizes, so all call
+ * vkrhip_exchange_configure with larger capacities and run again. The merged
+ * lists stay valid until the run after the next one. */
+int vkrhip_comm_unique_id(uint8_t *out_id128);
+int vkrhip_comm_init(vkrhip_ctx *ctx, const uint8_t *id128, uint32_t world, uint32_t rank);
+int vkrhip_exchange_configure(vkrhip_ctx *ctx, uint32_t world, uint32_t vis_cap, uint32_t key_cap);
+int vkrhip_exchange_run(vkrhip_ctx *ctx);
+int vkrhip_exchange_finish(vkrhip_ctx *ctx, uint64_t *result_out,
+                           const uint32_t **merged_visible_dev, const uint64_t **merged_keys_dev);
 
 /* scene_entity_is_visible (vkr_scene_system.c:1935-1977) for every node of a
  * hierarchy stored parents-first (the order vkrhip_levelize produces): walking up

@@ -308,3 +308,48 @@ def test_two_processes_one_gpu_over_gloo(oracle, tmp_path):
         assert (r0["merged_ranges"][v] == st["execution_ranges"]).all()
         count, off = int(st["visible_count"]), int(r0["view_offsets"][v])
         assert (r0["vis"][off: off + count] == whole["visible"][v, :count]).all()
+
+
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_native_exchange_single_rank(oracle, with_comm):
+    """The exchange inside the library (pack, RCCL all-gather or device copy,
+    merge on the second stream, two buffer sets): five frames in flight without a
+    host wait, growth from too-small blocks, result equal to the oracle."""
+    import torch
+    from helpers import oracle_frame, view_set
+    from vulkan_renderer_amd import HipScene, synth
+    from vulkan_renderer_amd.parallel import RcclExchange
+    n = 30000
+    vs = synth.camera_views(cascades=1)
+    planes, required = view_set(vs)
+    sc = synth.flat_scene(n, seed=4, blend_fraction=0.3)
+    sc.pos[:, :3] *= np.float32(0.3)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with HipScene(max_nodes=n, max_candidates=n, max_views=planes.shape[0]) as hs:
+        hs.set_hierarchy(None, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+        hs.set_views(planes, required, vs.view)
+        if with_comm:
+            hs.comm_init(hs.comm_unique_id(), 1, 0)      # a one-rank RCCL communicator
+        ex = RcclExchange(hs, 1, 0, planes.shape[0], vis_cap=256, key_cap=64)
+        for _ in range(3):
+            hs.mark_all(0x02)
+            hs.frame()
+            ex.run()
+        ex.finish()
+        assert ex.regrown == 1
+        for _ in range(5):
+            hs.mark_all(0x02)
+            hs.frame()
+            ex.run()
+        ex.finish()
+        assert ex.regrown == 1
+        keys = ex.key_merged.cpu().numpy().view(np.uint64)[: ex.transparent_total]
+        assert keys.shape[0] > 50 and (keys == ref["payload"]["sort_keys"]).all()
+        vis = ex.vis_merged.cpu().numpy().view(np.uint32)
+        for vi in range(planes.shape[0]):
+            st = ref["states"][vi]
+            assert (ex.merged_ranges[vi] == st["execution_ranges"]).all()
+            count, off = int(st["visible_count"]), int(ex.view_offsets[vi])
+            assert (vis[off: off + count] == ref["visible"][vi, :count]).all()

@@ -14,7 +14,8 @@
 //   k_exchange_plan   one block reads the G headers and writes the copy
 //                     descriptors, the run table and the merged ranges, and flags
 //                     a rank whose lists did not fit its block;
-//   k_concat_ranges   the segmented copy, k_exchange_merge_keys the rank merge.
+//   k_exchange_apply  the segmented copy of the visible lists and the rank merge
+//                     of the key runs, one launch.
 //
 // Block layout in 32-bit words, H = exchange_header_words(views):
 //   [0, views*8)            execution_ranges[view][bucket] = {offset, count}
@@ -219,10 +220,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_exchange_plan(ExchangePlanArgs a
 // Rank-based G-way merge of the gathered descending key runs (unique keys): the
 // output slot of a key is its index in its own run plus, for every other run,
 // the number of keys greater than it. The run table comes from k_exchange_plan.
-__global__ __launch_bounds__(256) void k_exchange_merge_keys(const uint32_t *gathered,
-                                                             const uint64_t *runs, uint32_t g,
-                                                             uint64_t *out) {
-  const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void exchange_merge_keys_block(const uint32_t *gathered,
+                                                          const uint64_t *runs, uint32_t g,
+                                                          uint64_t *out, uint64_t block) {
+  const uint64_t gid = block * 256u + threadIdx.x;
   uint32_t q = 0;
   uint64_t j = gid;
   while (q < g && j >= runs[64u + q]) {
@@ -246,6 +247,25 @@ __global__ __launch_bounds__(256) void k_exchange_merge_keys(const uint32_t *gat
     pos += lo;
   }
   out[pos] = key;
+}
+
+// The segmented copy of the visible lists and the key merge in one launch (both
+// only depend on the plan): blocks [0, copy_blocks) are a (descriptor, row) of
+// the copy, the rest merge keys.
+__global__ __launch_bounds__(256) void k_exchange_apply(const uint32_t *gathered, const uint64_t *desc,
+                                                        uint32_t descriptors, uint32_t rows,
+                                                        uint32_t *merged_visible,
+                                                        const uint64_t *runs, uint32_t g,
+                                                        uint64_t *merged_keys) {
+  const uint32_t copy_blocks = descriptors * rows;
+  if (blockIdx.x < copy_blocks) {
+    const uint32_t d = blockIdx.x / rows, row = blockIdx.x % rows;
+    const uint64_t src = desc[d * 3u + 0], dst = desc[d * 3u + 1], n = desc[d * 3u + 2];
+    for (uint64_t k = (uint64_t)row * 256u + threadIdx.x; k < n; k += (uint64_t)rows * 256u)
+      merged_visible[dst + k] = gathered[src + k];
+    return;
+  }
+  exchange_merge_keys_block(gathered, runs, g, merged_keys, blockIdx.x - copy_blocks);
 }
 
 }  // namespace vkr

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -154,6 +155,19 @@ struct vkrhip_ctx {
   DevBuf<uint64_t> epoch_maps, epoch_maps_low, epoch_wave_maps, epoch_pairs, epoch_result;
   DevBuf<uint8_t> epoch_enter_low, epoch_enter_high;
   DevBuf<uint32_t> epoch_wave_occluders;
+  // native exchange: RCCL communicator, second stream, two buffer sets
+  void *comm = nullptr;  // ncclComm_t
+  uint32_t comm_world = 1, comm_rank = 0;
+  hipStream_t xstream = nullptr;
+  hipEvent_t x_packed = nullptr;
+  struct ExchangeSet {
+    DevBuf<uint32_t> send, recv, merged_visible;
+    DevBuf<uint64_t> merged_keys, result;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+  } xset[2];
+  uint32_t x_world = 0, x_vis_cap = 0, x_key_cap = 0, x_turn = 0;
+  int x_last = -1;
   // device-planned exchange
   DevBuf<uint64_t> exch_desc, exch_rank_view_start, exch_prefix, exch_runs;
 
@@ -222,6 +236,63 @@ int bind_device(vkrhip_ctx *c) {
     int r_ = (expr);                 \
     if (r_ != VKRHIP_OK) return r_;  \
   } while (0)
+
+// RCCL is bound at run time (the library has no link-time dependency on it): a
+// process that already has it loaded (e.g. under PyTorch) is given that copy.
+struct RcclApi {
+  int (*GetUniqueId)(void *id128) = nullptr;
+  // ncclUniqueId is passed by value: a 128-byte struct
+  struct UniqueId {
+    char internal[128];
+  };
+  int (*CommInitRank)(void **comm, int nranks, UniqueId id, int rank) = nullptr;
+  int (*AllGather)(const void *send, void *recv, size_t count, int datatype, void *comm,
+                   hipStream_t stream) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool tried = false, ok = false;
+};
+RcclApi g_rccl;
+constexpr int kNcclUint32 = 3;  // ncclDataType_t: ncclUint32
+
+bool load_rccl() {
+  if (g_rccl.tried) return g_rccl.ok;
+  g_rccl.tried = true;
+  void *lib = nullptr;
+  const char *names[] = {"librccl.so.1", "librccl.so"};
+  for (const char *n : names)
+    if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  for (const char *n : names)
+    if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return false;
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllGather && g_rccl.CommDestroy;
+  return g_rccl.ok;
+}
+
+void release_exchange(vkrhip_ctx *c) {
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+  if (c->comm && g_rccl.ok) (void)g_rccl.CommDestroy(c->comm);
+  c->comm = nullptr;
+  for (auto &x : c->xset) {
+    dev_free(x.send);
+    dev_free(x.recv);
+    dev_free(x.merged_visible);
+    dev_free(x.merged_keys);
+    dev_free(x.result);
+    if (x.done) (void)hipEventDestroy(x.done);
+    x.done = nullptr;
+    x.in_flight = false;
+  }
+  if (c->x_packed) (void)hipEventDestroy(c->x_packed);
+  c->x_packed = nullptr;
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
+  c->xstream = nullptr;
+}
 
 // Timer scope: records an event pair around a stage when profiling is on.
 struct StageTimer {
@@ -445,6 +516,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->merge_ptrs);
   dev_free(c->merge_lens);
   dev_free(c->concat_desc);
+  release_exchange(c);
   dev_free(c->exch_desc);
   dev_free(c->transmission_list);
   dev_free(c->transmission_rows);
@@ -1530,11 +1602,14 @@ uint64_t vkrhip_exchange_block_words(uint32_t views, uint32_t vis_cap, uint32_t 
 
 uint64_t vkrhip_exchange_result_words(uint32_t views) { return exchange_result_words(views); }
 
-int vkrhip_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap) {
-  if (!c || !block_dev) return VKRHIP_ERR_ARG;
+}  // extern "C"
+
+namespace {
+
+int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap,
+                          hipEvent_t packed = nullptr) {
   if (!c->frame_ran || !(c->last_stages & VKRHIP_STAGE_CULL))
     return fail(c, VKRHIP_ERR_STATE, "exchange needs a frame that ran the cull stage");
-  TRY(bind_device(c));
   ExchangePackArgs a{};
   a.states = c->states.p;
   a.visible = c->visible.p;
@@ -1548,19 +1623,18 @@ int vkrhip_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, u
   a.have_keys = (c->last_stages & VKRHIP_STAGE_TRANSPARENT) && c->out_keys.p ? 1u : 0u;
   const uint64_t widest = std::max<uint64_t>(std::max(vis_cap, key_cap), 1);
   const unsigned blocks = (unsigned)std::min<uint64_t>(ceil_div(widest, 1024), 512);
-  hipLaunchKernelGGL(k_exchange_pack, dim3(blocks, c->views + 1u), dim3(256), 0, c->stream, a);
+  hipExtLaunchKernelGGL(k_exchange_pack, dim3(blocks, c->views + 1u), dim3(256), 0, c->stream, nullptr,
+                        packed, 0, a);
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
 
-int vkrhip_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t world,
-                          uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
-                          uint64_t *merged_keys_dev, uint64_t *result_dev) {
-  if (!c || !gathered_dev || !merged_visible_dev || !merged_keys_dev || !result_dev)
-    return VKRHIP_ERR_ARG;
+int enqueue_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t world,
+                           uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
+                           uint64_t *merged_keys_dev, uint64_t *result_dev, hipStream_t stream,
+                           hipEvent_t done = nullptr) {
   if (world == 0 || world > 64) return fail(c, VKRHIP_ERR_ARG, "world size %u outside 1..64", world);
   if (c->views == 0) return fail(c, VKRHIP_ERR_STATE, "no views set");
-  TRY(bind_device(c));
   const uint32_t pairs = c->views * 4u;
   TRY(dev_alloc(c, c->exch_desc, (size_t)pairs * world * 3));
   TRY(dev_alloc(c, c->exch_rank_view_start, (size_t)world * c->views));
@@ -1577,17 +1651,131 @@ int vkrhip_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t 
   a.views = c->views;
   a.vis_cap = vis_cap;
   a.key_cap = key_cap;
-  hipLaunchKernelGGL(k_exchange_plan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, a);
+  hipLaunchKernelGGL(k_exchange_plan, dim3(1), dim3(SCAN_BLOCK), 0, stream, a);
   // copy rows: enough blocks per descriptor to cover the largest possible range
   const unsigned rows = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vis_cap, 4096), 1), 64);
-  hipLaunchKernelGGL(k_concat_ranges, dim3(pairs * world, rows), dim3(256), 0, c->stream, gathered_dev,
-                     merged_visible_dev, c->exch_desc.p);
-  if (key_cap) {
-    const uint64_t most = (uint64_t)world * key_cap;
-    hipLaunchKernelGGL(k_exchange_merge_keys, dim3((unsigned)ceil_div(most, 256)), dim3(256), 0,
-                       c->stream, gathered_dev, c->exch_runs.p, world, merged_keys_dev);
-  }
+  const unsigned key_blocks = (unsigned)ceil_div((uint64_t)world * key_cap, 256);
+  // `done` (may be null) is recorded right behind the last kernel by the launch itself
+  hipExtLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
+                        nullptr, done, 0, gathered_dev, (const uint64_t *)c->exch_desc.p, pairs * world,
+                        rows, merged_visible_dev, (const uint64_t *)c->exch_runs.p, world,
+                        merged_keys_dev);
   HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vkrhip_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap) {
+  if (!c || !block_dev) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  return enqueue_exchange_pack(c, block_dev, vis_cap, key_cap);
+}
+
+int vkrhip_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t world,
+                          uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
+                          uint64_t *merged_keys_dev, uint64_t *result_dev, void *hip_stream) {
+  if (!c || !gathered_dev || !merged_visible_dev || !merged_keys_dev || !result_dev)
+    return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  return enqueue_exchange_merge(c, gathered_dev, world, vis_cap, key_cap, merged_visible_dev,
+                                merged_keys_dev, result_dev,
+                                hip_stream ? (hipStream_t)hip_stream : c->stream);
+}
+
+int vkrhip_comm_unique_id(uint8_t *out_id128) {
+  if (!out_id128) return VKRHIP_ERR_ARG;
+  if (!load_rccl()) return fail(nullptr, VKRHIP_ERR_STATE, "librccl.so could not be loaded");
+  const int rc = g_rccl.GetUniqueId(out_id128);
+  if (rc != 0) return fail(nullptr, VKRHIP_ERR_HIP, "ncclGetUniqueId failed (%d)", rc);
+  return VKRHIP_OK;
+}
+
+int vkrhip_comm_init(vkrhip_ctx *c, const uint8_t *id128, uint32_t world, uint32_t rank) {
+  if (!c || !id128 || world == 0 || world > 64 || rank >= world) return VKRHIP_ERR_ARG;
+  if (c->comm) return fail(c, VKRHIP_ERR_STATE, "the context already has a communicator");
+  if (!load_rccl()) return fail(c, VKRHIP_ERR_STATE, "librccl.so could not be loaded");
+  TRY(bind_device(c));
+  RcclApi::UniqueId id;
+  std::memcpy(id.internal, id128, sizeof(id.internal));
+  void *comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, (int)world, id, (int)rank);
+  if (rc != 0)
+    return fail(c, VKRHIP_ERR_HIP, "ncclCommInitRank failed: %s",
+                g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+  c->comm = comm;
+  c->comm_world = world;
+  c->comm_rank = rank;
+  return VKRHIP_OK;
+}
+
+int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, uint32_t key_cap) {
+  if (!c || world == 0 || world > 64) return VKRHIP_ERR_ARG;
+  if (c->comm ? world != c->comm_world : world != 1)
+    return fail(c, VKRHIP_ERR_STATE, "world %u does not match the communicator (%u)", world,
+                c->comm ? c->comm_world : 1u);
+  if (c->views == 0) return fail(c, VKRHIP_ERR_STATE, "no views set");
+  TRY(bind_device(c));
+  if (!c->xstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+  if (!c->x_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->x_packed, hipEventDisableTiming));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->xstream));
+  const uint64_t words = exchange_block_words(c->views, vis_cap, key_cap);
+  for (auto &x : c->xset) {
+    TRY(dev_alloc(c, x.send, words));
+    TRY(dev_alloc(c, x.recv, words * world));
+    TRY(dev_alloc(c, x.merged_visible, std::max<uint64_t>((uint64_t)world * vis_cap, 1)));
+    TRY(dev_alloc(c, x.merged_keys, std::max<uint64_t>((uint64_t)world * key_cap, 1)));
+    TRY(dev_alloc(c, x.result, exchange_result_words(VKRHIP_MAX_VIEWS)));
+    if (!x.done) HIP_TRY(c, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
+    x.in_flight = false;
+  }
+  c->x_world = world;
+  c->x_vis_cap = vis_cap;
+  c->x_key_cap = key_cap;
+  c->x_last = -1;
+  return VKRHIP_OK;
+}
+
+int vkrhip_exchange_run(vkrhip_ctx *c) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if (!c->x_world) return fail(c, VKRHIP_ERR_STATE, "vkrhip_exchange_configure has not been called");
+  TRY(bind_device(c));
+  const int k = (int)(c->x_turn++ & 1u);
+  auto &x = c->xset[k];
+  // the exchange that used this set two frames ago must be done with it
+  if (x.in_flight) HIP_TRY(c, hipStreamWaitEvent(c->stream, x.done, 0));
+  TRY(enqueue_exchange_pack(c, x.send.p, c->x_vis_cap, c->x_key_cap, c->x_packed));
+  HIP_TRY(c, hipStreamWaitEvent(c->xstream, c->x_packed, 0));
+  const uint64_t words = exchange_block_words(c->views, c->x_vis_cap, c->x_key_cap);
+  if (c->comm) {
+    const int rc = g_rccl.AllGather(x.send.p, x.recv.p, words, kNcclUint32, c->comm, c->xstream);
+    if (rc != 0)
+      return fail(c, VKRHIP_ERR_HIP, "ncclAllGather failed: %s",
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(x.recv.p, x.send.p, words * 4, hipMemcpyDeviceToDevice, c->xstream));
+  }
+  TRY(enqueue_exchange_merge(c, x.recv.p, c->x_world, c->x_vis_cap, c->x_key_cap, x.merged_visible.p,
+                             x.merged_keys.p, x.result.p, c->xstream, x.done));
+  x.in_flight = true;
+  c->x_last = k;
+  return VKRHIP_OK;
+}
+
+int vkrhip_exchange_finish(vkrhip_ctx *c, uint64_t *result_out, const uint32_t **merged_visible_dev,
+                           const uint64_t **merged_keys_dev) {
+  if (!c || !result_out) return VKRHIP_ERR_ARG;
+  if (c->x_last < 0) return fail(c, VKRHIP_ERR_STATE, "vkrhip_exchange_run has not been called");
+  TRY(bind_device(c));
+  auto &x = c->xset[c->x_last];
+  HIP_TRY(c, hipMemcpyAsync(result_out, x.result.p, exchange_result_words(c->views) * 8,
+                            hipMemcpyDeviceToHost, c->xstream));
+  HIP_TRY(c, hipStreamSynchronize(c->xstream));
+  if (merged_visible_dev) *merged_visible_dev = x.merged_visible.p;
+  if (merged_keys_dev) *merged_keys_dev = x.merged_keys.p;
   return VKRHIP_OK;
 }
 

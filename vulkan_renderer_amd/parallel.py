@@ -18,6 +18,11 @@ The host looks at the result words only in finish(): a rank whose lists did not
 fit the capacities is flagged there, every rank sees the same flags and grows
 its buffers alike, and the exchange of that frame is repeated.
 
+Collective and merge run on a stream of their own and the buffers exist twice,
+so the next frame starts as soon as the pack kernel has copied this frame's
+results out of the scene: the all-gather over xGMI and the merge kernels of
+frame k overlap the transform and cull of frame k+1.
+
 The reference is single-GPU; nothing here has a counterpart in it. The
 collective is a plain torch.distributed call, so the same exchange runs on
 `gloo` with CPU tensors in the tests (pack and merge are then served by a
@@ -142,11 +147,10 @@ def wrap_device(ptr: int, count: int, dtype):
 
 
 class HipShardSource:
-    """One rank's scene as ShardExchange sees it. Pack, merge and the collective
-    are enqueued on the stream the scene itself runs on (wrapped for torch as an
-    external stream), so they are ordered with the frame without any host wait.
-    A scene that was pointed at torch's default stream gets its own stream back:
-    the library reads a null handle as "use the private stream"."""
+    """One rank's scene as ShardExchange sees it. Pack is enqueued on the stream
+    the scene itself runs on (wrapped for torch as an external stream); the
+    collective and the merge go to a second stream, ordered after the pack by an
+    event - no host wait anywhere."""
 
     def __init__(self, scene):
         import torch
@@ -156,16 +160,46 @@ class HipShardSource:
         if scene.stream_handle() == 0:
             scene.set_stream(None)
         self.stream = torch.cuda.ExternalStream(scene.stream_handle(), device=self.device)
+        self.exchange_stream = torch.cuda.Stream(device=self.device)
 
-    def stream_scope(self):
+    def scene_scope(self):
         return self.torch.cuda.stream(self.stream)
+
+    def exchange_scope(self):
+        return self.torch.cuda.stream(self.exchange_stream)
 
     def pack(self, block, vis_cap: int, key_cap: int):
         self.scene.exchange_pack(block.data_ptr(), vis_cap, key_cap)
 
     def merge(self, gathered, world: int, vis_cap: int, key_cap: int, vis_merged, key_merged, result):
         self.scene.exchange_merge(gathered.data_ptr(), world, vis_cap, key_cap, vis_merged.data_ptr(),
-                                  key_merged.data_ptr(), result.data_ptr())
+                                  key_merged.data_ptr(), result.data_ptr(),
+                                  self.exchange_stream.cuda_stream)
+
+    def packed_event(self):
+        """Event after everything enqueued on the scene's stream so far."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def exchanged_event(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.exchange_stream)
+        return ev
+
+    def scene_wait(self, event):
+        self.stream.wait_event(event)
+
+    def exchange_wait(self, event):
+        self.exchange_stream.wait_event(event)
+
+    def synchronize(self):
+        self.stream.synchronize()
+        self.exchange_stream.synchronize()
+
+
+class _Buffers:
+    __slots__ = ("send", "recv", "vis_merged", "key_merged", "result", "done")
 
 
 class ShardExchange:
@@ -173,12 +207,12 @@ class ShardExchange:
 
     `source` provides pack() and merge() for this rank's frame (HipShardSource on
     a GPU; the CPU tests pass a numpy-backed stand-in and run the same exchange
-    over `gloo`). run() only enqueues; finish() waits, validates the capacities
-    (growing them and repeating the exchange when a rank overflowed) and fills
-    merged_ranges / view_offsets / visible_total / transparent_total. After
-    finish(): vis_merged holds, view after view, the merged visible list of
-    every (view, bucket) and key_merged[:transparent_total] the merged descending
-    draw keys - identical on every rank.
+    over `gloo`). run() only enqueues; finish() waits for the latest run,
+    validates the capacities (growing them and repeating the exchange when a rank
+    overflowed) and fills merged_ranges / view_offsets / visible_total /
+    transparent_total. After finish(): vis_merged holds, view after view, the
+    merged visible list of every (view, bucket) and key_merged[:transparent_total]
+    the merged descending draw keys - identical on every rank.
 
     Every rank must call run() and finish() in the same order: the capacities
     change only in finish(), from values every rank reads out of the same
@@ -195,45 +229,70 @@ class ShardExchange:
         self.source = source
         self.world, self.rank, self.views, self.group = world, rank, views, group
         self.device = device if device is not None else source.device
+        self.overlapped = hasattr(source, "exchange_scope")
+        self._scene_scope = source.scene_scope if self.overlapped else contextlib.nullcontext
+        self._exchange_scope = source.exchange_scope if self.overlapped else contextlib.nullcontext
         self.regrown = 0
         self.merged_ranges = None
         self.view_offsets = None
         self.visible_total = 0
         self.transparent_total = 0
-        scope = getattr(source, "stream_scope", None)
-        self._scope = scope if scope is not None else contextlib.nullcontext
-        with self._scope():
-            self.result = torch.zeros(exchange_result_words(views), dtype=torch.int64, device=self.device)
-            self._alloc(vis_cap, key_cap)
+        self.vis_merged = self.key_merged = None
+        self._turn = 0
+        self._alloc(vis_cap, key_cap)
 
     def _alloc(self, vis_cap: int, key_cap: int):
         torch = self.torch
         self.vis_cap, self.key_cap = _round_up4(max(vis_cap, 4)), _round_up4(max(key_cap, 4))
         words = exchange_block_words(self.views, self.vis_cap, self.key_cap)
-        self.send = torch.zeros(words, dtype=torch.int32, device=self.device)
-        self.recv = torch.zeros(self.world * words, dtype=torch.int32, device=self.device)
-        self.vis_merged = torch.zeros(self.world * self.vis_cap, dtype=torch.int32, device=self.device)
-        self.key_merged = torch.zeros(self.world * self.key_cap, dtype=torch.int64, device=self.device)
+        self._sets = []
+        with self._exchange_scope():
+            for _ in range(2 if self.overlapped else 1):
+                b = _Buffers()
+                b.send = torch.zeros(words, dtype=torch.int32, device=self.device)
+                b.recv = torch.zeros(self.world * words, dtype=torch.int32, device=self.device)
+                b.vis_merged = torch.zeros(self.world * self.vis_cap, dtype=torch.int32, device=self.device)
+                b.key_merged = torch.zeros(self.world * self.key_cap, dtype=torch.int64, device=self.device)
+                b.result = torch.zeros(exchange_result_words(self.views), dtype=torch.int64,
+                                       device=self.device)
+                b.done = None
+                self._sets.append(b)
+        if self.overlapped:
+            self.source.synchronize()  # the fills above ran on the exchange stream
+        self._last = None
 
     def run(self):
         """Enqueue pack, all-gather and merge of the frame that was just enqueued."""
         dist = self.torch.distributed
-        with self._scope():
-            self.source.pack(self.send, self.vis_cap, self.key_cap)
+        src = self.source
+        b = self._sets[self._turn % len(self._sets)]
+        self._turn += 1
+        if self.overlapped and b.done is not None:
+            src.scene_wait(b.done)  # the exchange that used this set two frames ago
+        with self._scene_scope():
+            src.pack(b.send, self.vis_cap, self.key_cap)
+        if self.overlapped:
+            src.exchange_wait(src.packed_event())
+        with self._exchange_scope():
             if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-                self.recv.copy_(self.send, non_blocking=True)
+                b.recv.copy_(b.send, non_blocking=True)
             else:
-                dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-            self.source.merge(self.recv, self.world, self.vis_cap, self.key_cap, self.vis_merged,
-                              self.key_merged, self.result)
+                dist.all_gather_into_tensor(b.recv, b.send, group=self.group)
+            src.merge(b.recv, self.world, self.vis_cap, self.key_cap, b.vis_merged, b.key_merged,
+                      b.result)
+        if self.overlapped:
+            b.done = src.exchanged_event()
+        self._last = b
         return self
 
     def finish(self):
-        """Wait for the exchange, repeat it with larger blocks if a rank overflowed."""
+        """Wait for the latest exchange, repeat it with larger blocks if a rank overflowed."""
         v = self.views
+        if self._last is None:
+            raise RuntimeError("finish() without run()")
         while True:
-            with self._scope():
-                res = self.result.cpu().numpy().view(np.uint64)  # waits for the stream
+            with self._exchange_scope():
+                res = self._last.result.cpu().numpy().view(np.uint64)  # waits for the exchange stream
             flags = int(res[0])
             if flags & FLAG_HEADER_MISMATCH:
                 raise RuntimeError("exchange blocks were packed for different view counts")
@@ -244,10 +303,78 @@ class ShardExchange:
                 vis_cap = int(int(res[1]) * 1.25) + 1024
             if int(res[2]) > key_cap:
                 key_cap = int(int(res[2]) * 1.25) + 1024
-            with self._scope():
-                self._alloc(vis_cap, key_cap)
+            if self.overlapped:
+                self.source.synchronize()
+            self._alloc(vis_cap, key_cap)
             self.regrown += 1
             self.run()
+        self.vis_merged, self.key_merged = self._last.vis_merged, self._last.key_merged
+        self.visible_total = int(res[3])
+        self.transparent_total = int(res[4])
+        self.view_offsets = res[RESULT_FIXED_WORDS: RESULT_FIXED_WORDS + v + 1].copy()
+        self.merged_ranges = res[RESULT_FIXED_WORDS + v + 1:].reshape(v, 4, 2).copy()
+        return self
+
+
+class RcclExchange:
+    """The same exchange run entirely inside the HIP library: pack, ncclAllGather
+    and merge are enqueued by one C call per frame (vkrhip_exchange_run) on the
+    library's two streams, so the host spends a few launches per frame instead of
+    a Python collective. torch.distributed is only used once, to hand rank 0's
+    RCCL unique id to the other ranks. Same interface and the same capacity
+    protocol as ShardExchange; world 1 needs no process group (the all-gather is
+    a device copy)."""
+
+    def __init__(self, scene, world: int, rank: int, views: int, group=None, vis_cap: int = 4096,
+                 key_cap: int = 1024):
+        import torch
+        self.torch = torch
+        self.scene, self.world, self.rank, self.views = scene, world, rank, views
+        if world > 1:
+            dist = torch.distributed
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.from_numpy(scene.comm_unique_id().copy())
+            backend = dist.get_backend(group)
+            if backend == "nccl":
+                uid = uid.cuda()
+            dist.broadcast(uid, src=0, group=group)
+            scene.comm_init(uid.cpu().numpy(), world, rank)
+        self.regrown = 0
+        self.merged_ranges = None
+        self.view_offsets = None
+        self.visible_total = 0
+        self.transparent_total = 0
+        self.vis_merged = self.key_merged = None
+        self._configure(vis_cap, key_cap)
+
+    def _configure(self, vis_cap: int, key_cap: int):
+        self.vis_cap, self.key_cap = _round_up4(max(vis_cap, 4)), _round_up4(max(key_cap, 4))
+        self.scene.exchange_configure(self.world, self.vis_cap, self.key_cap)
+
+    def run(self):
+        self.scene.exchange_run()
+        return self
+
+    def finish(self):
+        v = self.views
+        while True:
+            res, vis_ptr, key_ptr = self.scene.exchange_finish(v)
+            flags = int(res[0])
+            if flags & FLAG_HEADER_MISMATCH:
+                raise RuntimeError("exchange blocks were packed for different view counts")
+            if not flags & (FLAG_VISIBLE_TRUNCATED | FLAG_KEYS_TRUNCATED):
+                break
+            vis_cap, key_cap = self.vis_cap, self.key_cap
+            if int(res[1]) > vis_cap:
+                vis_cap = int(int(res[1]) * 1.25) + 1024
+            if int(res[2]) > key_cap:
+                key_cap = int(int(res[2]) * 1.25) + 1024
+            self._configure(vis_cap, key_cap)
+            self.regrown += 1
+            self.run()
+        self.vis_merged = wrap_device(vis_ptr, self.world * self.vis_cap, self.torch.int32)
+        self.key_merged = wrap_device(key_ptr, self.world * self.key_cap, self.torch.int64)
         self.visible_total = int(res[3])
         self.transparent_total = int(res[4])
         self.view_offsets = res[RESULT_FIXED_WORDS: RESULT_FIXED_WORDS + v + 1].copy()

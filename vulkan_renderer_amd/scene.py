@@ -373,6 +373,33 @@ class HipScene:
                                                desc.shape[0]))
 
 
+    # ---- the exchange inside the library, over RCCL --------------------------
+    def comm_unique_id(self) -> np.ndarray:
+        out = np.zeros(128, np.uint8)
+        rc = self.lib.vkrhip_comm_unique_id(N.ptr(out))
+        if rc != N.OK:
+            msg = self.lib.vkrhip_last_error(None)
+            raise N.VkrHipError(rc, msg.decode() if msg else "")
+        return out
+
+    def comm_init(self, unique_id, world: int, rank: int) -> None:
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.shape == (128,)
+        self._ok(self.lib.vkrhip_comm_init(self.ctx, N.ptr(uid), world, rank))
+
+    def exchange_configure(self, world: int, vis_cap: int, key_cap: int) -> None:
+        self._ok(self.lib.vkrhip_exchange_configure(self.ctx, world, vis_cap, key_cap))
+
+    def exchange_run(self) -> None:
+        self._ok(self.lib.vkrhip_exchange_run(self.ctx))
+
+    def exchange_finish(self, views: int):
+        """(result words, merged visible device pointer, merged keys device pointer)."""
+        res = np.zeros(self.exchange_result_words(views), np.uint64)
+        vis, keys = C.c_void_p(), C.c_void_p()
+        self._ok(self.lib.vkrhip_exchange_finish(self.ctx, N.ptr(res), C.byref(vis), C.byref(keys)))
+        return res, int(vis.value or 0), int(keys.value or 0)
+
     def candidate_epoch(self):
         """(hash, occluder_count) of vkr_vk_candidate_epoch
         (lib/src/renderer/vulkan/vkr_vulkan_draws.c:19-44) for the current candidates
@@ -392,9 +419,11 @@ class HipScene:
         self._ok(self.lib.vkrhip_exchange_pack(self.ctx, block_ptr, vis_cap, key_cap))
 
     def exchange_merge(self, gathered_ptr: int, world: int, vis_cap: int, key_cap: int,
-                       merged_visible_ptr: int, merged_keys_ptr: int, result_ptr: int) -> None:
+                       merged_visible_ptr: int, merged_keys_ptr: int, result_ptr: int,
+                       stream: int | None = None) -> None:
         self._ok(self.lib.vkrhip_exchange_merge(self.ctx, gathered_ptr, world, vis_cap, key_cap,
-                                                merged_visible_ptr, merged_keys_ptr, result_ptr))
+                                                merged_visible_ptr, merged_keys_ptr, result_ptr,
+                                                stream))
 
 
 # ---- host-side leaf mirrors ---------------------------------------------
