@@ -186,8 +186,21 @@ def main() -> int:
     exchange = None
     if world > 1 or args.exchange:
         # the library's own RCCL exchange; the torch collective only for the gloo rehearsal
-        exchange = (ShardExchange(hs, world, rank, views) if args.backend == "gloo" and world > 1
-                    else RcclExchange(hs, world, rank, views))
+        native = not (args.backend == "gloo" and world > 1)
+        if native:
+            try:
+                exchange = RcclExchange(hs, world, rank, views)
+            except Exception as exc:  # no usable RCCL: the torch-driven exchange does the same work
+                print(f"bench.py: native RCCL exchange unavailable ({exc}); using torch.distributed",
+                      file=sys.stderr)
+                native = False
+        if world > 1:  # every rank must take the same path
+            flag = torch.tensor([1 if native else 0], dtype=torch.int32,
+                                device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
+        if not native:
+            exchange = ShardExchange(hs, world, rank, views)
 
     dirty_bits = N.DIRTY_LOCAL if args.dirty == "local" else N.DIRTY_WORLD
 
