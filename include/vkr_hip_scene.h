@@ -304,6 +304,20 @@ int vkrhip_merge_runs(vkrhip_ctx *ctx, uint32_t g, const uint64_t *const *runs_k
 int vkrhip_concat_ranges(vkrhip_ctx *ctx, const uint32_t *src_dev, uint32_t *dst_dev,
                          const uint64_t *desc, uint32_t n_desc);
 
+/* ---- occlusion of the camera view against a depth pyramid (the HZB branch of
+ * vk_gpu_draw_classify: vkr_vk_candidate_occluded,
+ * lib/src/renderer/shaders/vulkan/slang/world/deferred.slang:240-303,340-347;
+ * host gates lib/src/renderer/vulkan/vkr_vulkan_deferred.c:298-366) ------------
+ * mips: mip_count levels, mip 0 first, each row-major with extent
+ * max(extent >> mip, 1), one float (farthest depth) per texel; view_projection:
+ * the camera's, column-major (root.view_projections[0]). While a pyramid is set,
+ * rows of view 0 that pass the frustum and have valid bounds are tested against
+ * it; occluded rows leave view 0 and are counted in
+ * views[0].occlusion_culled_count. NULL mips or mip_count 0 switch the test off
+ * (root.hzb_enabled == 0). Waits for the context's stream; the data is copied. */
+int vkrhip_set_hzb(vkrhip_ctx *ctx, const float *mips, uint32_t width, uint32_t height,
+                   uint32_t mip_count, const float *view_projection, float depth_epsilon);
+
 /* ---- candidate epoch (replaces vkr_vk_candidate_epoch,
  * lib/src/renderer/vulkan/vkr_vulkan_draws.c:9-44) -----------------------------
  * 64-bit FNV-1a over mesh, geometry, submesh_index, material, instance.model,

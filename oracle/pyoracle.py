@@ -140,6 +140,12 @@ def _u32(a):
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
+class Hzb(C.Structure):
+    _fields_ = [("mips", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("mip_count", C.c_uint32), ("depth_epsilon", C.c_float),
+                ("view_projection", C.c_float * 16)]
+
+
 class Oracle:
     """Array-shaped front end of libvkr_oracle.so."""
 
@@ -193,6 +199,10 @@ class Oracle:
         L.vko_encode_visible_rows.argtypes = [vp, u32p, vp, vp]
         L.vko_entity_is_visible.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
         L.vko_entity_is_visible.restype = C.c_int
+        L.vko_set_hzb.argtypes = [vp]
+        L.vko_set_hzb.restype = None
+        L.vko_hzb_occluded.argtypes = [vp, vp, C.c_float]
+        L.vko_hzb_occluded.restype = C.c_int
         L.vko_candidate_epoch.argtypes = [vp, C.c_uint32]
         L.vko_candidate_epoch.restype = C.c_uint64
         L.vko_merge_runs_desc.argtypes = [vp, u64p, C.c_uint32, u64p]
@@ -431,6 +441,27 @@ class Oracle:
         n = parent.shape[0]
         return np.array([self.lib.vko_entity_is_visible(parent.ctypes.data, spec.ctypes.data, n, i)
                          for i in range(n)], np.uint8)
+
+    def set_hzb(self, mips, width=0, height=0, view_projection=None, depth_epsilon=0.0):
+        """Depth pyramid for view 0 of the following multiview_cull* calls (None: off)."""
+        if mips is None:
+            self._hzb = None
+            self.lib.vko_set_hzb(None)
+            return
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(m, np.float32).reshape(-1) for m in mips]))
+        h = Hzb()
+        h.mips = flat.ctypes.data
+        h.width, h.height, h.mip_count = width, height, len(mips)
+        h.depth_epsilon = depth_epsilon
+        vp = np.asarray(view_projection, np.float32).reshape(16)
+        for k in range(16):
+            h.view_projection[k] = float(vp[k])
+        self._hzb = (h, flat)  # keeps the memory alive
+        self.lib.vko_set_hzb(C.byref(h))
+
+    def hzb_occluded(self, center3, radius):
+        c = np.ascontiguousarray(center3, dtype=np.float32)
+        return bool(self.lib.vko_hzb_occluded(C.byref(self._hzb[0]), c.ctypes.data, float(radius)))
 
     def candidate_epoch(self, candidates):
         c = np.ascontiguousarray(candidates)

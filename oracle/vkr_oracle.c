@@ -651,6 +651,70 @@ uint32_t vko_build_world_payload(const float *world16, const uint32_t *node,
 /* Multi-view cull + compaction                                              */
 /* ======================================================================== */
 
+/* deferred.slang:240-303 */
+static const vko_hzb *g_hzb = NULL;
+void vko_set_hzb(const vko_hzb *hzb) { g_hzb = hzb; }
+
+static uint32_t vko_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static float vko_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+int vko_hzb_occluded(const vko_hzb *h, const float *center, float world_radius) {
+  if (!h || !h->mips || h->mip_count == 0u || h->width == 0u || h->height == 0u)
+    return 0;
+  const float radius = fmaxf(world_radius, 0.0f);
+  float ndc_min[2] = {1e30f, 1e30f}, ndc_max[2] = {-1e30f, -1e30f};
+  float nearest_depth = 1.0f;
+  for (uint32_t corner = 0; corner < 8u; ++corner) {
+    const float p[4] = {center[0] + ((corner & 1u) ? 1.0f : -1.0f) * radius,
+                        center[1] + ((corner & 2u) ? 1.0f : -1.0f) * radius,
+                        center[2] + ((corner & 4u) ? 1.0f : -1.0f) * radius, 1.0f};
+    float clip[4];
+    vko_mat4_mul_vec4(h->view_projection, p, clip);
+    if (!isfinite(clip[0]) || !isfinite(clip[1]) || !isfinite(clip[2]) || !isfinite(clip[3]) ||
+        clip[3] <= 1e-6f)
+      return 0;
+    const float nx = clip[0] / clip[3], ny = clip[1] / clip[3], nz = clip[2] / clip[3];
+    ndc_min[0] = fminf(ndc_min[0], nx);
+    ndc_min[1] = fminf(ndc_min[1], ny);
+    ndc_max[0] = fmaxf(ndc_max[0], nx);
+    ndc_max[1] = fmaxf(ndc_max[1], ny);
+    nearest_depth = fminf(nearest_depth, nz);
+  }
+  if (nearest_depth <= 0.0f || ndc_min[0] > 1.0f || ndc_min[1] > 1.0f || ndc_max[0] < -1.0f ||
+      ndc_max[1] < -1.0f)
+    return 0;
+  const float uv_min[2] = {vko_clamp01(ndc_min[0] * 0.5f + 0.5f), vko_clamp01(-ndc_max[1] * 0.5f + 0.5f)};
+  const float uv_max[2] = {vko_clamp01(ndc_max[0] * 0.5f + 0.5f), vko_clamp01(-ndc_min[1] * 0.5f + 0.5f)};
+  const uint32_t extent[2] = {h->width, h->height};
+  uint32_t base_min[2], base_max[2];
+  for (int k = 0; k < 2; ++k) {
+    base_min[k] = vko_min_u32((uint32_t)floorf(uv_min[k] * (float)extent[k]), extent[k] - 1u);
+    base_max[k] = vko_min_u32((uint32_t)floorf(uv_max[k] * (float)extent[k]), extent[k] - 1u);
+  }
+  const uint32_t span_x = base_max[0] - base_min[0] + 1u, span_y = base_max[1] - base_min[1] + 1u;
+  const uint32_t max_span = span_x > span_y ? span_x : span_y;
+  uint32_t mip = 0;
+  if (max_span > 1u) /* floor(log2(float(max_span))): exact as a bit scan below 2^24 */
+    mip = 31u - (uint32_t)__builtin_clz(max_span);
+  mip = vko_min_u32(mip, h->mip_count - 1u);
+  uint64_t offset = 0;
+  for (uint32_t m = 0; m < mip; ++m) {
+    const uint32_t w = (h->width >> m) ? (h->width >> m) : 1u, ht = (h->height >> m) ? (h->height >> m) : 1u;
+    offset += (uint64_t)w * ht;
+  }
+  const uint32_t mw = (h->width >> mip) ? (h->width >> mip) : 1u;
+  const uint32_t mh = (h->height >> mip) ? (h->height >> mip) : 1u;
+  const uint32_t x0 = vko_min_u32(base_min[0] >> mip, mw - 1u), x1 = vko_min_u32(base_max[0] >> mip, mw - 1u);
+  const uint32_t y0 = vko_min_u32(base_min[1] >> mip, mh - 1u), y1 = vko_min_u32(base_max[1] >> mip, mh - 1u);
+  for (uint32_t y = y0; y <= y1; ++y)
+    for (uint32_t x = x0; x <= x1; ++x) {
+      const float occluder_depth = h->mips[offset + (uint64_t)y * mw + x];
+      if (nearest_depth <= occluder_depth + h->depth_epsilon)
+        return 0;
+    }
+  return 1;
+}
+
 static void vko_multiview_core(const float *const *models, const float *sphere4,
                                uint64_t sphere_stride, const uint32_t *flags,
                                uint64_t flags_stride, const uint32_t *bucket,
@@ -699,6 +763,12 @@ static void vko_multiview_core(const float *const *models, const float *sphere4,
         }
         if (!vis) {
           cls[i] = VKO_CULLED;
+          continue;
+        }
+        /* deferred.slang:340-347: view 0 only, rows with valid bounds only */
+        if (v == 0u && g_hzb && vko_hzb_occluded(g_hzb, c4, radius)) {
+          cls[i] = VKO_CULLED;
+          st.occlusion_culled_count++;
           continue;
         }
       }

@@ -280,6 +280,24 @@ void vko_multiview_cull(const vko_world_candidate *candidates, uint64_t n,
                         vko_compaction_state *states, uint32_t *visible,
                         uint64_t *near_plane_ties);
 
+/* HZB occlusion of view 0: vkr_vk_candidate_occluded, deferred.slang:240-303. The
+ * shader leaves the order of its float operations to the compiler; this
+ * restatement fixes one (every * and + rounded on its own, the matrix products in
+ * the order of mat4_mul_vec4, IEEE division, floor(log2) of the integer span as a
+ * bit scan). Nothing in the reference pins the bits of this step.
+ *   mips: mip 0 first, each row-major with extent max(extent >> mip, 1);
+ *   view_projection: column-major, the camera's (view_projections[0]).
+ * vko_set_hzb(NULL) switches the test off; while set, vko_multiview_cull* apply
+ * it to view 0 and count states[0].occlusion_culled_count. */
+typedef struct vko_hzb {
+  const float *mips;
+  uint32_t width, height, mip_count;
+  float depth_epsilon;
+  float view_projection[16];
+} vko_hzb;
+void vko_set_hzb(const vko_hzb *hzb);
+int vko_hzb_occluded(const vko_hzb *hzb, const float *world_center3, float world_radius);
+
 /* Same, from flat arrays (no 144-byte rows): sphere[i*4] = local bounding
  * sphere, flags[i], bucket[i], model taken from world16[node[i]]. */
 void vko_multiview_cull_flat(const float *world16, const uint32_t *node,

@@ -172,3 +172,23 @@ class OracleShardSource:
             res[4] = keys.shape[0]
             vis_merged.numpy().view(np.uint32)[: merged.shape[0]] = merged
             key_merged.numpy().view(np.uint64)[: keys.shape[0]] = keys
+
+
+# ---- synthetic depth pyramid (tests of the HZB occlusion branch) ----------------
+def depth_pyramid(width, height, walls, background=1.0):
+    """Mip chain (farthest depth per texel, 2x2 max reduction, extent >> mip) of a
+    depth image that is `background` except for axis-aligned rectangles
+    (x0, y0, x1, y1, depth) in texels."""
+    img = np.full((height, width), background, np.float32)
+    for x0, y0, x1, y1, d in walls:
+        img[y0:y1, x0:x1] = np.float32(d)
+    mips = [img]
+    while mips[-1].shape[0] > 1 or mips[-1].shape[1] > 1:
+        src = mips[-1]
+        h, w = max(src.shape[0] >> 1, 1), max(src.shape[1] >> 1, 1)
+        dst = np.empty((h, w), np.float32)
+        for y in range(h):
+            for x in range(w):
+                dst[y, x] = src[min(2 * y, src.shape[0] - 1): 2 * y + 2, min(2 * x, src.shape[1] - 1): 2 * x + 2].max()
+        mips.append(dst)
+    return mips

@@ -1,0 +1,77 @@
+"""The occlusion branch of the camera view's classify (vkr_vk_candidate_occluded,
+deferred.slang:240-303) against a synthetic depth pyramid: the HIP path and the
+CPU checker read the same pyramid and must agree on every visible list, count and
+the occlusion counter. The shader fixes no float operation order, so the checker
+is the reference for the bits here (parity unpinned by the reference itself)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle, sc, cascades, mips, w, h, eps, **scene_kw):
+    from helpers import compare_frame, hip_scene_for, oracle_frame, view_set
+    from vulkan_renderer_amd import mat4_mul, synth
+    vs = synth.camera_views(cascades=cascades, far=900.0)
+    planes, required = view_set(vs)
+    vp = mat4_mul(vs.projection, vs.view)
+    oracle.set_hzb(mips, w, h, vp, eps)
+    try:
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    finally:
+        oracle.set_hzb(None)
+    plain = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, planes.shape[0], **scene_kw) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.set_hzb(mips, w, h, vp, eps)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        occluded = int(ref["states"][0]["occlusion_culled_count"])
+        assert info.views[0].occlusion_culled_count == occluded
+        # switching the pyramid off restores the plain result (and the fused kernel)
+        hs.set_hzb(None)
+        hs.mark_all(0x02)
+        hs.frame()
+        compare_frame(hs, plain, sc)
+    return occluded, int(plain["states"][0]["visible_count"]), int(ref["states"][0]["visible_count"])
+
+
+def test_wall_hides_what_is_behind_it(oracle):
+    from helpers import depth_pyramid
+    from vulkan_renderer_amd import synth
+    sc = synth.flat_scene(60000, seed=11, blend_fraction=0.1)
+    w, h = 96, 64
+    # a wall over the left two thirds of the screen at ndc depth 0.99 (about ten units away)
+    mips = depth_pyramid(w, h, [(0, 0, 64, 64, 0.99)])
+    assert len(mips) == 7
+    occluded, before, after = _run(oracle, sc, 2, mips, w, h, 1e-5)
+    assert occluded > 200 and after == before - occluded and after > 50
+
+
+def test_far_pyramid_hides_nothing_and_near_pyramid_everything(oracle):
+    from helpers import depth_pyramid
+    from vulkan_renderer_amd import synth
+    sc = synth.deep_scene(20000, depth=5, seed=6, fanout=5, roots=4, blend_fraction=0.2,
+                          no_bounds_fraction=0.05)
+    occluded, before, after = _run(oracle, sc, 0, depth_pyramid(33, 17, []), 33, 17, 0.0)
+    assert occluded == 0 and after == before
+    occluded, before, after = _run(oracle, sc, 0, depth_pyramid(33, 17, [(0, 0, 33, 17, 0.0)]), 33, 17, 0.0)
+    # rows without valid bounds are never tested (deferred.slang:245), nor rows whose cube
+    # reaches behind the near plane
+    assert occluded > 0 and 0 < after < before
+
+
+def test_single_level_pyramid_and_node_mapping(oracle):
+    """mip_count 1 (every rectangle is walked texel by texel at mip 0) with several
+    rows per transform."""
+    from helpers import depth_pyramid
+    from vulkan_renderer_amd import synth
+    sc = synth.deep_scene(3000, depth=4, seed=4, fanout=6, roots=3)
+    rng = np.random.default_rng(5)
+    n_cand = 9000
+    node = rng.integers(0, sc.n, n_cand).astype(np.uint32)
+    ident, matbits, bounds = synth.make_candidates(9, np.arange(n_cand, dtype=np.uint64), blend_fraction=0.25)
+    sc.node, sc.ident, sc.matbits, sc.bounds = node, ident, matbits, bounds
+    mips = depth_pyramid(24, 24, [(4, 4, 20, 20, 0.995)])[:1]
+    occluded, before, after = _run(oracle, sc, 1, mips, 24, 24, 1e-4)
+    assert occluded > 0 and after == before - occluded

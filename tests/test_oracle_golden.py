@@ -254,3 +254,26 @@ def test_effective_visibility_equals_the_parent_chain_walk(oracle):
         got_s = np.empty(n, np.uint8)
         got_s[order] = effective_visibility(new_parent, spec_s[order])
         assert (got_s == expect_s).all()
+
+
+def test_hzb_occlusion_hand_cases(oracle):
+    """vko_hzb_occluded on cases that can be checked by hand (deferred.slang:240-303)."""
+    from helpers import depth_pyramid
+    from vulkan_renderer_amd import mat4_mul, synth
+    vs = synth.camera_views(cascades=0)          # at the origin, looking down -Z, near 0.1, far 400
+    vp = mat4_mul(vs.projection, vs.view)
+    w, h = 64, 64
+    # wall over the left half at the depth of z = -10: ndc z = far/(far-near) * (1 - near/10)
+    wall = np.float32(400.0 / 399.9 * (1.0 - 0.1 / 10.0))
+    oracle.set_hzb(depth_pyramid(w, h, [(0, 0, 32, 64, wall)]), w, h, vp, 0.0)
+    try:
+        assert oracle.hzb_occluded([-20.0, 0.0, -50.0], 1.0)        # left, behind the wall
+        assert not oracle.hzb_occluded([-3.0, 0.0, -5.0], 0.5)      # left, in front of it
+        assert not oracle.hzb_occluded([20.0, 0.0, -50.0], 1.0)     # right half: background
+        assert not oracle.hzb_occluded([0.0, 0.0, -50.0], 2.0)      # straddles the wall's edge
+        assert not oracle.hzb_occluded([0.0, 0.0, 5.0], 1.0)        # behind the camera: w <= 0
+        assert not oracle.hzb_occluded([-1.0, 0.0, -0.5], 1.0)      # cube reaches behind the near plane
+        assert oracle.hzb_occluded([-20.0, 0.0, -50.0], float("nan"))  # max(NaN, 0) = 0: a point
+        assert oracle.hzb_occluded([-20.0, 0.0, -50.0], -5.0)       # negative radius clamps to 0
+    finally:
+        oracle.set_hzb(None)

@@ -58,6 +58,7 @@ enum : int {
   CNT_TRANSMISSION = 4,
   CNT_TRANSPARENT = 5,        // clamped to capacity
   CNT_TRANSPARENT_TOTAL = 6,  // before the clamp
+  CNT_OCCLUDED = 7,           // view 0 rows rejected by the depth pyramid
   CNT_COUNT = 8
 };
 // Counters that every block adds to are kept in STAT_SHARDS copies (block b uses
@@ -136,6 +137,12 @@ struct CullArgs {
   uint64_t seg_stride;
   uint64_t index_base;
   uint32_t views;
+  // depth pyramid of view 0 (k_classify<.., HZB = true> only)
+  const float *hzb;            // mip 0 first, row-major, extent of mip m = max(extent >> m, 1)
+  const uint32_t *hzb_offset;  // first texel of every mip
+  const float4 *hzb_view_projection;  // the camera's, four columns
+  uint32_t hzb_width, hzb_height, hzb_mips;
+  float hzb_epsilon;
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -145,7 +152,7 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 //   cnt   [CULL_SLOTS][rows]  survivors per (round, wave) slot and row; turned into
 //                             start positions inside the segment when it is done
 //   bits  [CULL_ROUNDS][words][CULL_BLOCK]  per-view verdict bits of every candidate
-//   ties  [views], stat [4]
+//   ties  [views], stat [5]
 struct CullShared {
   uint32_t *cnt;
   uint32_t *bits;
@@ -158,7 +165,7 @@ struct CullShared {
 __host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
   const uint32_t rows = views * 4u + 1u, words = (views + 31u) / 32u;
   return sizeof(uint32_t) * ((size_t)CULL_SLOTS * rows + (size_t)CULL_ROUNDS * words * CULL_BLOCK +
-                             views + 4u);
+                             views + 5u);
 }
 
 __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
@@ -172,16 +179,72 @@ __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
   s.stat = s.ties + views;
   const uint32_t t = threadIdx.x;
   // cnt, bits (rounds a block does not run must read as "nobody survives"), ties, stat
-  const uint32_t total = CULL_SLOTS * s.rows + CULL_ROUNDS * s.words * CULL_BLOCK + views + 4u;
+  const uint32_t total = CULL_SLOTS * s.rows + CULL_ROUNDS * s.words * CULL_BLOCK + views + 5u;
   for (uint32_t k = t; k < total; k += blockDim.x) cull_lds[k] = 0u;
   return s;
+}
+
+// vkr_vk_candidate_occluded, deferred.slang:240-303: the screen rectangle of the
+// world sphere's bounding cube picks a pyramid level where it spans at most a
+// few texels; the row is occluded when its nearest depth lies behind every texel
+// it touches. The shader leaves the order of its float operations open; this is
+// the order the CPU checker uses (separately rounded * and +, products summed as
+// (c0 x + c1 y) + (c2 z + c3 w), IEEE division, floor(log2) of the integer span
+// as a bit scan).
+__device__ __forceinline__ bool hzb_occluded(const CullArgs &a, float cx, float cy, float cz,
+                                             float world_radius) {
+  const float radius = fmaxf(world_radius, 0.0f);
+  const uniform_ptr<float> vp = as_uniform(a.hzb_view_projection);
+  float min_x = 1e30f, min_y = 1e30f, max_x = -1e30f, max_y = -1e30f, nearest = 1.0f;
+  bool usable = true;
+#pragma unroll
+  for (uint32_t corner = 0; corner < 8u; ++corner) {
+    const float x = cx + ((corner & 1u) ? 1.0f : -1.0f) * radius;
+    const float y = cy + ((corner & 2u) ? 1.0f : -1.0f) * radius;
+    const float z = cz + ((corner & 4u) ? 1.0f : -1.0f) * radius;
+    float clip[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      clip[r] = (vp[r] * x + vp[4 + r] * y) + (vp[8 + r] * z + vp[12 + r] * 1.0f);
+    usable = usable && isfinite(clip[0]) && isfinite(clip[1]) && isfinite(clip[2]) &&
+             isfinite(clip[3]) && !(clip[3] <= 1e-6f);
+    const float nx = clip[0] / clip[3], ny = clip[1] / clip[3], nz = clip[2] / clip[3];
+    min_x = fminf(min_x, nx);
+    min_y = fminf(min_y, ny);
+    max_x = fmaxf(max_x, nx);
+    max_y = fmaxf(max_y, ny);
+    nearest = fminf(nearest, nz);
+  }
+  // a corner that cannot be projected ends the test in the shader; later corners
+  // then no longer matter, so their (possibly non-finite) results are dropped here
+  if (!usable) return false;
+  if (nearest <= 0.0f || min_x > 1.0f || min_y > 1.0f || max_x < -1.0f || max_y < -1.0f) return false;
+  const float u0 = fminf(fmaxf(min_x * 0.5f + 0.5f, 0.0f), 1.0f);
+  const float v0 = fminf(fmaxf(-max_y * 0.5f + 0.5f, 0.0f), 1.0f);
+  const float u1 = fminf(fmaxf(max_x * 0.5f + 0.5f, 0.0f), 1.0f);
+  const float v1 = fminf(fmaxf(-min_y * 0.5f + 0.5f, 0.0f), 1.0f);
+  const uint32_t bx0 = min((uint32_t)floorf(u0 * (float)a.hzb_width), a.hzb_width - 1u);
+  const uint32_t by0 = min((uint32_t)floorf(v0 * (float)a.hzb_height), a.hzb_height - 1u);
+  const uint32_t bx1 = min((uint32_t)floorf(u1 * (float)a.hzb_width), a.hzb_width - 1u);
+  const uint32_t by1 = min((uint32_t)floorf(v1 * (float)a.hzb_height), a.hzb_height - 1u);
+  const uint32_t span = max(bx1 - bx0 + 1u, by1 - by0 + 1u);
+  uint32_t mip = span > 1u ? 31u - (uint32_t)__clz((int)span) : 0u;
+  mip = min(mip, a.hzb_mips - 1u);
+  const uint32_t mw = max(a.hzb_width >> mip, 1u), mh = max(a.hzb_height >> mip, 1u);
+  const uint32_t x0 = min(bx0 >> mip, mw - 1u), x1 = min(bx1 >> mip, mw - 1u);
+  const uint32_t y0 = min(by0 >> mip, mh - 1u), y1 = min(by1 >> mip, mh - 1u);
+  const float *level = a.hzb + a.hzb_offset[mip];
+  for (uint32_t y = y0; y <= y1; ++y)
+    for (uint32_t x = x0; x <= x1; ++x)
+      if (nearest <= level[(uint64_t)y * mw + x] + a.hzb_epsilon) return false;
+  return true;
 }
 
 // Classifies one candidate against every view. Must be called by all threads of
 // the wave (it votes). `valid` lanes own candidate i with model matrix m;
 // `round` is the candidate's 256-wide round inside its segment. Returns the
 // lane's state bucket (bits 0-3) and blend-row visibility (bit 4).
-template <bool TIES, bool BOUNDS_OUT>
+template <bool TIES, bool BOUNDS_OUT, bool HZB = false>
 __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullShared &s,
                                                        uint32_t round, uint64_t i, bool valid,
                                                        const Mat4 &m, float4 ls, uint32_t cf) {
@@ -260,6 +323,12 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
       if (TIES) {
         const unsigned long long mtie = __ballot(tie);
         if (leader && mtie) atomicAdd(&s.ties[v], (uint32_t)__popcll(mtie));
+      }
+      if (HZB && v == 0u) {  // deferred.slang:340-347
+        const bool occluded = pass && bounds_valid && hzb_occluded(a, c.x, c.y, c.z, radius);
+        pass = pass && !occluded;
+        const unsigned long long mocc = __ballot(occluded);
+        if (leader && mocc) atomicAdd(&s.stat[4], (uint32_t)__popcll(mocc));
       }
       if (pass) bits |= 1u << (v & 31u);
       const unsigned long long mp = __ballot(pass);
@@ -351,6 +420,7 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     if (s.stat[1]) atomicAdd(&shard[CNT_CULLED_CAMERA], s.stat[1]);
     if (s.stat[2]) atomicAdd(&shard[CNT_CAMERA_OPAQUE], s.stat[2]);
     if (s.stat[3]) atomicAdd(&shard[CNT_TRANSMISSION], s.stat[3]);
+    if (s.stat[4]) atomicAdd(&shard[CNT_OCCLUDED], s.stat[4]);
   }
   if (TIES)
     for (uint32_t r = t; r < a.views; r += blockDim.x)
@@ -369,7 +439,7 @@ __device__ __forceinline__ void segment_empty(const CullArgs &a, uint64_t seg) {
 // 256. With the identity candidate->node mapping the matrices arrive as
 // coalesced 16-byte loads staged through LDS (thread t then reads its own four
 // columns); otherwise each thread gathers its node's matrix.
-template <bool IDENTITY, bool TIES, bool BOUNDS_OUT>
+template <bool IDENTITY, bool TIES, bool BOUNDS_OUT, bool HZB = false>
 __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
   __shared__ float4 s_mat[IDENTITY ? CULL_BLOCK * MAT_LDS_STRIDE : 1];
   CullShared s = cull_shared_init(a.views);
@@ -422,8 +492,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
       m.c[2] = p[2];
       m.c[3] = p[3];
     }
-    packed |= classify_candidate<TIES, BOUNDS_OUT>(a, s, (uint32_t)round, i, valid, m, ls_r[round],
-                                                   cf)
+    packed |= classify_candidate<TIES, BOUNDS_OUT, HZB>(a, s, (uint32_t)round, i, valid, m,
+                                                        ls_r[round], cf)
               << (8 * round);
   }
   segment_finish<TIES>(a, s, seg, first, 0u, packed);

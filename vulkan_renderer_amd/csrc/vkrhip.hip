@@ -83,6 +83,13 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> required;
   DevBuf<float4> camera_view;
 
+  // depth pyramid of view 0 (vkrhip_set_hzb); hzb_mips == 0: occlusion test off
+  DevBuf<float> hzb;
+  DevBuf<uint32_t> hzb_offset;
+  DevBuf<float4> hzb_view_projection;
+  uint32_t hzb_width = 0, hzb_height = 0, hzb_mips = 0;
+  float hzb_epsilon = 0.f;
+
   // cull intermediates / outputs
   DevBuf<uint8_t> tvis;
   DevBuf<CompactionState> states;
@@ -517,6 +524,9 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->merge_lens);
   dev_free(c->concat_desc);
   release_exchange(c);
+  dev_free(c->hzb);
+  dev_free(c->hzb_offset);
+  dev_free(c->hzb_view_projection);
   dev_free(c->exch_desc);
   dev_free(c->transmission_list);
   dev_free(c->transmission_rows);
@@ -922,6 +932,13 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.seg_stride = c->seg_stride;
   a.index_base = c->cfg.source_index_base;
   a.views = c->views;
+  a.hzb = c->hzb.p;
+  a.hzb_offset = c->hzb_offset.p;
+  a.hzb_view_projection = c->hzb_view_projection.p;
+  a.hzb_width = c->hzb_width;
+  a.hzb_height = c->hzb_height;
+  a.hzb_mips = c->hzb_mips;
+  a.hzb_epsilon = c->hzb_epsilon;
   return a;
 }
 
@@ -1029,6 +1046,20 @@ static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned g
                                     bool bounds_out) {
   const dim3 g(grid), b(CULL_BLOCK);
   const size_t lds = cull_shared_bytes(a.views);
+  if (a.hzb_mips) {  // the occlusion variants
+    if (ties) {
+      if (bounds_out)
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, true, true>, g, b, lds, a);
+      else
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, false, true>, g, b, lds, a);
+    } else {
+      if (bounds_out)
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, false, true, true>, g, b, lds, a);
+      else
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, false, false, true>, g, b, lds, a);
+    }
+    return;
+  }
   if (ties) {
     if (bounds_out)
       launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, true>, g, b, lds, a);
@@ -1230,7 +1261,8 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
       HIP_TRY(c, hipMemsetAsync(c->counter_block(c->cur_block), 0, vkrhip_ctx::kBlockBytes, c->stream));
     c->block_clean[c->cur_block] = false;
     // the fused kernel serves scenes that draw node i with candidate i
-    const bool fused = cull && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
+    // (the occlusion test lives in the stand-alone classify kernel only)
+    const bool fused = cull && c->hzb_mips == 0 && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
                        c->n_cand > 0 && c->n_cand <= c->n_nodes && c->level_offsets.size() > 1;
     if (fused) {
       TRY(launch_fused(c, bounds_out));
@@ -1272,6 +1304,7 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) {
     for (uint32_t v = 0; v < VKRHIP_MAX_VIEWS; ++v)
       out->near_plane_ties[v] += tie_shards[(size_t)sh * VKRHIP_MAX_VIEWS + v];
   const bool culled = (c->last_stages & VKRHIP_STAGE_CULL) != 0;
+  if (c->views) out->views[0].occlusion_culled_count = cnt[CNT_OCCLUDED];
   out->stats.objects_tested = culled ? (uint32_t)c->n_cand : 0u;
   out->stats.objects_culled_camera = cnt[CNT_CULLED_CAMERA];
   out->stats.objects_without_bounds = cnt[CNT_WITHOUT_BOUNDS];
@@ -1544,6 +1577,37 @@ int vkrhip_merge_runs(vkrhip_ctx *c, uint32_t g, const uint64_t *const *runs_key
   hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, c->stream,
                      c->merge_ptrs.p, c->merge_lens.p, g, total, out_keys_dev);
   HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
+int vkrhip_set_hzb(vkrhip_ctx *c, const float *mips, uint32_t width, uint32_t height,
+                   uint32_t mip_count, const float *view_projection, float depth_epsilon) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!mips || mip_count == 0 || width == 0 || height == 0) {  // deferred.slang:243-245: test off
+    c->hzb_mips = 0;
+    return VKRHIP_OK;
+  }
+  if (!view_projection) return fail(c, VKRHIP_ERR_ARG, "null view_projection");
+  if (mip_count > 32) return fail(c, VKRHIP_ERR_ARG, "mip_count %u > 32", mip_count);
+  uint32_t offsets[32];
+  uint64_t texels = 0;
+  for (uint32_t m = 0; m < mip_count; ++m) {
+    offsets[m] = (uint32_t)texels;
+    texels += (uint64_t)std::max(width >> m, 1u) * std::max(height >> m, 1u);
+    if (texels > 0xffffffffull) return fail(c, VKRHIP_ERR_CAPACITY, "depth pyramid too large");
+  }
+  TRY(dev_alloc(c, c->hzb, texels));
+  TRY(dev_alloc(c, c->hzb_offset, 32));
+  TRY(dev_alloc(c, c->hzb_view_projection, 4));
+  HIP_TRY(c, hipMemcpy(c->hzb.p, mips, texels * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->hzb_offset.p, offsets, mip_count * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->hzb_view_projection.p, view_projection, 64, hipMemcpyHostToDevice));
+  c->hzb_width = width;
+  c->hzb_height = height;
+  c->hzb_mips = mip_count;
+  c->hzb_epsilon = depth_epsilon;
   return VKRHIP_OK;
 }
 

@@ -70,6 +70,7 @@ class ViewState:
     visible_count: int
     overflow_count: int
     near_plane_ties: int
+    occlusion_culled_count: int = 0
 
 
 @dataclass
@@ -241,7 +242,8 @@ class HipScene:
                 bucket_counts=np.array(list(st.bucket_counts), np.uint32),
                 bucket_cursors=np.array(list(st.bucket_cursors), np.uint32),
                 visible_count=int(st.visible_count), overflow_count=int(st.overflow_count),
-                near_plane_ties=int(info.near_plane_ties[v])))
+                near_plane_ties=int(info.near_plane_ties[v]),
+                occlusion_culled_count=int(st.occlusion_culled_count)))
         return FrameResult(
             objects_tested=info.stats.objects_tested,
             objects_culled_camera=info.stats.objects_culled_camera,
@@ -399,6 +401,18 @@ class HipScene:
         vis, keys = C.c_void_p(), C.c_void_p()
         self._ok(self.lib.vkrhip_exchange_finish(self.ctx, N.ptr(res), C.byref(vis), C.byref(keys)))
         return res, int(vis.value or 0), int(keys.value or 0)
+
+    def set_hzb(self, mips, width: int = 0, height: int = 0, view_projection=None,
+                depth_epsilon: float = 0.0) -> None:
+        """Depth pyramid of the camera view (deferred.slang:240-303): `mips` is a list
+        of 2-D float32 arrays, mip 0 first; None switches the occlusion test off."""
+        if mips is None:
+            self._ok(self.lib.vkrhip_set_hzb(self.ctx, None, 0, 0, 0, None, 0.0))
+            return
+        flat = np.ascontiguousarray(np.concatenate([N.as_f32(m).reshape(-1) for m in mips]))
+        vp = N.as_f32(view_projection).reshape(16)
+        self._ok(self.lib.vkrhip_set_hzb(self.ctx, N.ptr(flat), width, height, len(mips), N.ptr(vp),
+                                         depth_epsilon))
 
     def candidate_epoch(self):
         """(hash, occluder_count) of vkr_vk_candidate_epoch
