@@ -176,16 +176,27 @@ __device__ __forceinline__ uniform_ptr<float> as_uniform(const float4 *p) {
 // vkr_frustum_test_sphere, lib/src/math/vkr_frustum.c:68-84, without the early
 // return (the result is the conjunction either way). planes = 6 x (nx,ny,nz,d).
 // A NaN distance or radius compares false and keeps the sphere visible.
+//
+// Two planes are evaluated side by side on two-wide vectors, which the
+// compiler maps to the packed fp32 instructions (v_pk_mul_f32, v_pk_add_f32):
+// every lane of a packed operation is the same separately rounded IEEE
+// operation as its scalar form. The "+ 0" of the reference's dot product is
+// left out: adding +0 can only turn a -0 sum into +0, and the distance is only
+// compared against -radius, where the sign of a zero makes no difference.
+typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool sphere_visible(uniform_ptr<float> planes, float cx, float cy,
                                                float cz, float radius) {
   bool culled = false;
   const float neg_r = -radius;
+  const float2v x = {cx, cx}, y = {cy, cy}, z = {cz, cz};
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const float dist =
-        dot3(planes[i * 4 + 0], planes[i * 4 + 1], planes[i * 4 + 2], cx, cy, cz) +
-        planes[i * 4 + 3];
-    culled = culled || (dist < neg_r);
+  for (int i = 0; i < 6; i += 2) {
+    const float2v nx = {planes[i * 4 + 0], planes[i * 4 + 4]};
+    const float2v ny = {planes[i * 4 + 1], planes[i * 4 + 5]};
+    const float2v nz = {planes[i * 4 + 2], planes[i * 4 + 6]};
+    const float2v d = {planes[i * 4 + 3], planes[i * 4 + 7]};
+    const float2v dist = ((nx * x + ny * y) + nz * z) + d;
+    culled = culled || (dist.x < neg_r) || (dist.y < neg_r);
   }
   return !culled;
 }
