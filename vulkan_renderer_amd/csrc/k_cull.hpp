@@ -148,39 +148,49 @@ struct CullArgs {
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 // LDS working set of one classify block, carved out of dynamic shared memory
-// (its size depends on the view count):
-//   cnt   [CULL_SLOTS][rows]  survivors per (round, wave) slot and row; turned into
-//                             start positions inside the segment when it is done
-//   bits  [CULL_ROUNDS][words][CULL_BLOCK]  per-view verdict bits of every candidate
+// (its size depends on the view count). A slot is one (round, wave) pair, i.e.
+// 64 consecutive candidates:
+//   mask  [CULL_SLOTS][views]   lanes of the slot that survive the view (ballot)
+//   inb   [CULL_SLOTS][4]       lanes of the slot per state bucket
+//   tmask [CULL_SLOTS]          lanes of the slot that are visible blend rows
+//   cnt   [CULL_SLOTS][rows]    filled when the segment ends: start position of the
+//                               slot's survivors of a row inside the segment
 //   ties  [views], stat [5]
 struct CullShared {
+  unsigned long long *mask;
+  unsigned long long *inb;
+  unsigned long long *tmask;
   uint32_t *cnt;
-  uint32_t *bits;
   uint32_t *ties;
   uint32_t *stat;
   uint32_t rows;
-  uint32_t words;
+  uint32_t views;
 };
 
+__host__ __device__ inline size_t cull_shared_words(uint32_t views) {
+  const uint32_t rows = views * 4u + 1u;
+  return 2u * ((size_t)CULL_SLOTS * views + CULL_SLOTS * 4u + CULL_SLOTS) + (size_t)CULL_SLOTS * rows +
+         views + 5u;
+}
 __host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
-  const uint32_t rows = views * 4u + 1u, words = (views + 31u) / 32u;
-  return sizeof(uint32_t) * ((size_t)CULL_SLOTS * rows + (size_t)CULL_ROUNDS * words * CULL_BLOCK +
-                             views + 5u);
+  return sizeof(uint32_t) * cull_shared_words(views);
 }
 
 __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
-  extern __shared__ uint32_t cull_lds[];
+  extern __shared__ unsigned long long cull_lds64[];  // 8-byte aligned
+  uint32_t *cull_lds = reinterpret_cast<uint32_t *>(cull_lds64);
   CullShared s;
   s.rows = views * 4u + 1u;
-  s.words = (views + 31u) >> 5;
-  s.cnt = cull_lds;
-  s.bits = s.cnt + CULL_SLOTS * s.rows;
-  s.ties = s.bits + CULL_ROUNDS * s.words * CULL_BLOCK;
+  s.views = views;
+  s.mask = cull_lds64;
+  s.inb = s.mask + CULL_SLOTS * views;
+  s.tmask = s.inb + CULL_SLOTS * 4u;
+  s.cnt = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
+  s.ties = s.cnt + CULL_SLOTS * s.rows;
   s.stat = s.ties + views;
-  const uint32_t t = threadIdx.x;
-  // cnt, bits (rounds a block does not run must read as "nobody survives"), ties, stat
-  const uint32_t total = CULL_SLOTS * s.rows + CULL_ROUNDS * s.words * CULL_BLOCK + views + 5u;
-  for (uint32_t k = t; k < total; k += blockDim.x) cull_lds[k] = 0u;
+  // everything starts at zero: slots a block does not run must read as "nobody survives"
+  const uint32_t total = (uint32_t)cull_shared_words(views);
+  for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) cull_lds[k] = 0u;
   return s;
 }
 
@@ -249,7 +259,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
                                                        uint32_t round, uint64_t i, bool valid,
                                                        const Mat4 &m, float4 ls, uint32_t cf) {
   const bool leader = lane_id() == 0;
-  uint32_t *cnt = s.cnt + (round * (CULL_BLOCK / 64u) + (threadIdx.x >> 6)) * s.rows;
+  const uint32_t slot = round * (CULL_BLOCK / 64u) + (threadIdx.x >> 6);
   // world sphere: vkr_visibility.c:40-49 / deferred.slang:325-333
   const float3 c = mat4_mul_point(m, ls.x, ls.y, ls.z);
   const float radius = ls.w * max_basis_length(m);
@@ -289,7 +299,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     const unsigned long long mo = __ballot(valid && (cf & CF_CAMERA_OPAQUE));
     const unsigned long long mx = __ballot(valid && (cf & CF_TRANSMISSIVE));
     if (leader) {
-      cnt[a.views * 4u] = (uint32_t)__popcll(mt);
+      s.tmask[slot] = mt;
       if (mb) atomicAdd(&s.stat[0], (uint32_t)__popcll(mb));
       if (mc) atomicAdd(&s.stat[1], (uint32_t)__popcll(mc));
       if (mo) atomicAdd(&s.stat[2], (uint32_t)__popcll(mo));
@@ -298,46 +308,39 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   }
 
   // views: deferred.slang:316-351
-  unsigned long long in_bucket[4];  // lanes of the wave per state bucket (wave-uniform)
 #pragma unroll
-  for (uint32_t q = 0; q < 4u; ++q) in_bucket[q] = __ballot(bucket == q);
-  for (uint32_t w = 0; w < s.words; ++w) {
-    uint32_t bits = 0u;
-    const uint32_t vend = min(a.views, (w + 1u) * 32u);
-    for (uint32_t v = w * 32u; v < vend; ++v) {
-      const uint32_t req = required[v];
-      bool pass = valid && bucket < 4u && !(cf & CF_UNPUBLISHED) && (cf & req) == req;
-      bool tie = false;
-      if (pass && bounds_valid) {
-        const uniform_ptr<float> vp = planes + v * 24u;
-        pass = sphere_visible(vp, c.x, c.y, c.z, radius);
-        if (TIES) {
+  for (uint32_t q = 0; q < 4u; ++q) {
+    const unsigned long long in_bucket = __ballot(bucket == q);
+    if (leader) s.inb[slot * 4u + q] = in_bucket;
+  }
+  for (uint32_t v = 0; v < a.views; ++v) {
+    const uint32_t req = required[v];
+    bool pass = valid && bucket < 4u && !(cf & CF_UNPUBLISHED) && (cf & req) == req;
+    bool tie = false;
+    if (pass && bounds_valid) {
+      const uniform_ptr<float> vp = planes + v * 24u;
+      pass = sphere_visible(vp, c.x, c.y, c.z, radius);
+      if (TIES) {
 #pragma unroll
-          for (int p = 0; p < 6; ++p) {
-            const float dist =
-                dot3(vp[p * 4 + 0], vp[p * 4 + 1], vp[p * 4 + 2], c.x, c.y, c.z) + vp[p * 4 + 3];
-            tie = tie || (fabsf(dist + radius) <= tie_eps[v * 6u + p]);
-          }
+        for (int p = 0; p < 6; ++p) {
+          const float dist =
+              dot3(vp[p * 4 + 0], vp[p * 4 + 1], vp[p * 4 + 2], c.x, c.y, c.z) + vp[p * 4 + 3];
+          tie = tie || (fabsf(dist + radius) <= tie_eps[v * 6u + p]);
         }
       }
-      if (TIES) {
-        const unsigned long long mtie = __ballot(tie);
-        if (leader && mtie) atomicAdd(&s.ties[v], (uint32_t)__popcll(mtie));
-      }
-      if (HZB && v == 0u) {  // deferred.slang:340-347
-        const bool occluded = pass && bounds_valid && hzb_occluded(a, c.x, c.y, c.z, radius);
-        pass = pass && !occluded;
-        const unsigned long long mocc = __ballot(occluded);
-        if (leader && mocc) atomicAdd(&s.stat[4], (uint32_t)__popcll(mocc));
-      }
-      if (pass) bits |= 1u << (v & 31u);
-      const unsigned long long mp = __ballot(pass);
-      if (leader) {
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) cnt[v * 4u + q] = (uint32_t)__popcll(mp & in_bucket[q]);
-      }
     }
-    s.bits[(round * s.words + w) * CULL_BLOCK + threadIdx.x] = bits;
+    if (TIES) {
+      const unsigned long long mtie = __ballot(tie);
+      if (leader && mtie) atomicAdd(&s.ties[v], (uint32_t)__popcll(mtie));
+    }
+    if (HZB && v == 0u) {  // deferred.slang:340-347
+      const bool occluded = pass && bounds_valid && hzb_occluded(a, c.x, c.y, c.z, radius);
+      pass = pass && !occluded;
+      const unsigned long long mocc = __ballot(occluded);
+      if (leader && mocc) atomicAdd(&s.stat[4], (uint32_t)__popcll(mocc));
+    }
+    const unsigned long long mp = __ballot(pass);
+    if (leader) s.mask[slot * a.views + v] = mp;
   }
   return (bucket & 0xfu) | (tv ? 0x10u : 0u);
 }
@@ -358,14 +361,19 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
   const uint32_t wave = t >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   __syncthreads();
-  // Sixteen lanes per row: exclusive prefix over the (round, wave) slots in
-  // candidate order. A wave holds the four bucket rows of one view, so the
+  // Sixteen lanes per row: the slot's survivors of the row (its view's mask cut
+  // to the row's bucket), then an exclusive prefix over the (round, wave) slots
+  // in candidate order. A wave holds the four bucket rows of one view, so the
   // starts of buckets 1-3 behind bucket 0 come from three shuffles.
   for (uint32_t r0 = 0; r0 < s.rows; r0 += CULL_BLOCK / CULL_SLOTS) {
     const uint32_t slot = t % CULL_SLOTS;
     const uint32_t r = r0 + t / CULL_SLOTS;
     const bool live = r < s.rows;
-    const uint32_t c = live ? s.cnt[slot * s.rows + r] : 0u;
+    uint32_t c = 0u;
+    if (live)
+      c = r < a.views * 4u
+              ? (uint32_t)__popcll(s.mask[slot * a.views + (r >> 2)] & s.inb[slot * 4u + (r & 3u)])
+              : (uint32_t)__popcll(s.tmask[slot]);
     uint32_t incl = c;
 #pragma unroll
     for (uint32_t d = 1; d < CULL_SLOTS; d <<= 1) {
@@ -388,28 +396,20 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     const uint32_t bucket = (packed >> (8u * round)) & 0xfu;
     const bool tv = ((packed >> (8u * round)) & 0x10u) != 0u;
     const uint32_t rel = round * CULL_BLOCK + t - tile_to_first;  // candidate index - first
-    const uint32_t *start = s.cnt + (round * (CULL_BLOCK / 64u) + wave) * s.rows;
-    unsigned long long below_same_bucket = 0ull;  // lower lanes holding this lane's bucket
-#pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) {
-      const unsigned long long mb = __ballot(bucket == q);
-      if (bucket == q) below_same_bucket = mb & lt_mask;
-    }
-    for (uint32_t w = 0; w < s.words; ++w) {
-      const uint32_t bits = s.bits[(round * s.words + w) * CULL_BLOCK + t];
-      if (__ballot(bits != 0u) == 0ull) continue;  // nobody of the wave survives these views
-      const uint32_t vend = min(a.views, (w + 1u) * 32u);
-      for (uint32_t v = w * 32u; v < vend; ++v) {
-        const bool pass = (bits >> (v & 31u)) & 1u;
-        const unsigned long long mp = __ballot(pass);
-        if (pass) {
-          const uint32_t pos = start[v * 4u + bucket] + (uint32_t)__popcll(mp & below_same_bucket);
-          a.stage[(uint64_t)v * a.stage_stride + first + pos] = (uint32_t)first + rel;
-        }
+    const uint32_t slot = round * (CULL_BLOCK / 64u) + wave;
+    const uint32_t *start = s.cnt + slot * s.rows;
+    // lower lanes holding this lane's bucket
+    const unsigned long long below_same_bucket = bucket < 4u ? s.inb[slot * 4u + bucket] & lt_mask : 0ull;
+    for (uint32_t v = 0; v < a.views; ++v) {
+      const unsigned long long mp = s.mask[slot * a.views + v];  // the same for the whole wave
+      if (mp == 0ull) continue;
+      if ((mp >> lane) & 1ull) {
+        const uint32_t pos = start[v * 4u + bucket] + (uint32_t)__popcll(mp & below_same_bucket);
+        a.stage[(uint64_t)v * a.stage_stride + first + pos] = (uint32_t)first + rel;
       }
     }
-    const unsigned long long mt = __ballot(tv);
     if (tv) {
+      const unsigned long long mt = s.tmask[slot];
       const uint32_t pos = start[a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
       a.stage[(uint64_t)a.views * a.stage_stride + first + pos] = (uint32_t)first + rel;
     }
