@@ -318,6 +318,17 @@ int vkrhip_concat_ranges(vkrhip_ctx *ctx, const uint32_t *src_dev, uint32_t *dst
 int vkrhip_set_hzb(vkrhip_ctx *ctx, const float *mips, uint32_t width, uint32_t height,
                    uint32_t mip_count, const float *view_projection, float depth_epsilon);
 
+/* The pyramid built on the device from a depth image (vk_hzb_build,
+ * deferred.slang:970-998): level 0 is texel min(xy, source extent - 1) of the
+ * source_width x source_height depth image at width x height; every further
+ * level is the maximum, starting from 0, of the 2x2 texels of the level above
+ * (clamped at its edge), extent max(extent >> level, 1). Then as vkrhip_set_hzb.
+ * depth is host memory. vkrhip_read_hzb copies one level back. */
+int vkrhip_build_hzb(vkrhip_ctx *ctx, const float *depth, uint32_t source_width,
+                     uint32_t source_height, uint32_t width, uint32_t height, uint32_t mip_count,
+                     const float *view_projection, float depth_epsilon);
+int vkrhip_read_hzb(vkrhip_ctx *ctx, uint32_t mip, float *out);
+
 /* ---- candidate epoch (replaces vkr_vk_candidate_epoch,
  * lib/src/renderer/vulkan/vkr_vulkan_draws.c:9-44) -----------------------------
  * 64-bit FNV-1a over mesh, geometry, submesh_index, material, instance.model,

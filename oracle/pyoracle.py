@@ -199,6 +199,8 @@ class Oracle:
         L.vko_encode_visible_rows.argtypes = [vp, u32p, vp, vp]
         L.vko_entity_is_visible.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
         L.vko_entity_is_visible.restype = C.c_int
+        L.vko_build_hzb.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.vko_build_hzb.restype = None
         L.vko_set_hzb.argtypes = [vp]
         L.vko_set_hzb.restype = None
         L.vko_hzb_occluded.argtypes = [vp, vp, C.c_float]
@@ -458,6 +460,19 @@ class Oracle:
             h.view_projection[k] = float(vp[k])
         self._hzb = (h, flat)  # keeps the memory alive
         self.lib.vko_set_hzb(C.byref(h))
+
+    def build_hzb(self, depth, width, height, mip_count):
+        """List of levels built from a depth image (vk_hzb_build)."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        extents = [(max(height >> m, 1), max(width >> m, 1)) for m in range(mip_count)]
+        flat = np.zeros(sum(h * w for h, w in extents), np.float32)
+        self.lib.vko_build_hzb(depth.ctypes.data, depth.shape[1], depth.shape[0], width, height,
+                               mip_count, flat.ctypes.data)
+        out, pos = [], 0
+        for h, w in extents:
+            out.append(flat[pos: pos + h * w].reshape(h, w).copy())
+            pos += h * w
+        return out
 
     def hzb_occluded(self, center3, radius):
         c = np.ascontiguousarray(center3, dtype=np.float32)

@@ -656,6 +656,37 @@ static const vko_hzb *g_hzb = NULL;
 void vko_set_hzb(const vko_hzb *hzb) { g_hzb = hzb; }
 
 static uint32_t vko_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+/* deferred.slang:970-998 */
+void vko_build_hzb(const float *depth, uint32_t sw, uint32_t sh, uint32_t width, uint32_t height,
+                   uint32_t mip_count, float *mips) {
+  const float *src = depth;
+  float *dst = mips;
+  for (uint32_t m = 0; m < mip_count; ++m) {
+    const uint32_t w = (width >> m) ? (width >> m) : 1u, h = (height >> m) ? (height >> m) : 1u;
+    for (uint32_t y = 0; y < h; ++y)
+      for (uint32_t x = 0; x < w; ++x) {
+        float out;
+        if (m == 0) { /* source_is_depth == 2: a clamped copy */
+          out = src[(uint64_t)vko_min_u32(y, sh - 1u) * sw + vko_min_u32(x, sw - 1u)];
+        } else {
+          out = 0.0f;
+          for (uint32_t dy = 0; dy < 2u; ++dy)
+            for (uint32_t dx = 0; dx < 2u; ++dx) {
+              const uint32_t px = vko_min_u32(x * 2u + dx, sw - 1u);
+              const uint32_t py = vko_min_u32(y * 2u + dy, sh - 1u);
+              out = fmaxf(out, src[(uint64_t)py * sw + px]);
+            }
+        }
+        dst[(uint64_t)y * w + x] = out;
+      }
+    src = dst;
+    sw = w;
+    sh = h;
+    dst += (uint64_t)w * h;
+  }
+}
+
 static float vko_clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
 int vko_hzb_occluded(const vko_hzb *h, const float *center, float world_radius) {

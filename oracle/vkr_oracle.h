@@ -262,8 +262,9 @@ uint32_t vko_build_world_payload(const float *world16, const uint32_t *node,
                                  uint32_t *counts);
 
 /* ------------------------------------------------------------------------
- * Multi-view cull + compaction semantics (deferred.slang:225-238,305-420 with
- * HZB excluded; host side vkr_vulkan_deferred.c:242-295).
+ * Multi-view cull + compaction semantics (deferred.slang:225-238,305-420; the HZB
+ * branch only while vko_set_hzb holds a pyramid; host side
+ * vkr_vulkan_deferred.c:242-295).
  *   planes: V x 24 floats; required_flags[v]
  *   classification[v*n + i] = bucket or VKO_CULLED
  *   states[v]; visible[v*visible_stride + k] = candidate index, bucket-major,
@@ -295,6 +296,9 @@ typedef struct vko_hzb {
   float depth_epsilon;
   float view_projection[16];
 } vko_hzb;
+/* vk_hzb_build, deferred.slang:970-998: all levels into `mips` (level 0 first). */
+void vko_build_hzb(const float *depth, uint32_t source_width, uint32_t source_height,
+                   uint32_t width, uint32_t height, uint32_t mip_count, float *mips);
 void vko_set_hzb(const vko_hzb *hzb);
 int vko_hzb_occluded(const vko_hzb *hzb, const float *world_center3, float world_radius);
 

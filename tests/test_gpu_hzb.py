@@ -75,3 +75,37 @@ def test_single_level_pyramid_and_node_mapping(oracle):
     mips = depth_pyramid(24, 24, [(4, 4, 20, 20, 0.995)])[:1]
     occluded, before, after = _run(oracle, sc, 1, mips, 24, 24, 1e-4)
     assert occluded > 0 and after == before - occluded
+
+
+@pytest.mark.parametrize("sw,sh,w,h,mips", [(64, 64, 64, 64, 7), (97, 55, 97, 55, 7), (130, 70, 65, 35, 4),
+                                            (5, 3, 5, 3, 3), (1, 1, 1, 1, 1)])
+def test_pyramid_built_on_the_device(oracle, sw, sh, w, h, mips):
+    """vk_hzb_build (deferred.slang:970-998): every level equals the CPU checker's,
+    odd extents, a source larger than level 0, negative and NaN depths included;
+    the frame that follows uses it like an uploaded pyramid."""
+    from helpers import compare_frame, hip_scene_for, oracle_frame, view_set
+    from vulkan_renderer_amd import mat4_mul, synth
+    rng = np.random.default_rng(sw * 131 + sh)
+    depth = rng.uniform(0.9, 1.0, (sh, sw)).astype(np.float32)
+    depth[rng.uniform(size=depth.shape) < 0.02] = np.float32(-0.5)
+    depth[rng.uniform(size=depth.shape) < 0.01] = np.float32("nan")
+    expect = oracle.build_hzb(depth, w, h, mips)
+    sc = synth.flat_scene(20000, seed=3, blend_fraction=0.1)
+    vs = synth.camera_views(cascades=0, far=900.0)
+    planes, required = view_set(vs)
+    vp = mat4_mul(vs.projection, vs.view)
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.build_hzb(depth, w, h, mips, vp, 1e-5)
+        for m in range(mips):
+            got = hs.read_hzb(m)
+            assert got.shape == expect[m].shape
+            assert got.tobytes() == expect[m].tobytes(), f"level {m}"
+        oracle.set_hzb(expect, w, h, vp, 1e-5)
+        try:
+            ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+        finally:
+            oracle.set_hzb(None)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        assert info.views[0].occlusion_culled_count == int(ref["states"][0]["occlusion_culled_count"])

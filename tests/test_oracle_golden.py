@@ -277,3 +277,29 @@ def test_hzb_occlusion_hand_cases(oracle):
         assert oracle.hzb_occluded([-20.0, 0.0, -50.0], -5.0)       # negative radius clamps to 0
     finally:
         oracle.set_hzb(None)
+
+
+def test_hzb_build_matches_a_numpy_statement(oracle):
+    """vko_build_hzb against the 2x2 maximum written with numpy slices (non-negative
+    depths, so the shader's starting value 0 does not show), plus its two special
+    rules: level 0 is a clamped copy, and nothing below 0 survives a reduction."""
+    from helpers import depth_pyramid
+    rng = np.random.default_rng(3)
+    for w, h in ((64, 32), (37, 21), (1, 9)):
+        depth = rng.uniform(0.0, 1.0, (h, w)).astype(np.float32)
+        expect = depth_pyramid(w, h, [])          # structure only; fill level 0 with the image
+        expect[0] = depth
+        for m in range(1, len(expect)):
+            src = expect[m - 1]
+            hh, ww = expect[m].shape
+            for y in range(hh):
+                for x in range(ww):
+                    expect[m][y, x] = src[min(2 * y, src.shape[0] - 1): 2 * y + 2,
+                                          min(2 * x, src.shape[1] - 1): 2 * x + 2].max()
+        got = oracle.build_hzb(depth, w, h, len(expect))
+        for m, level in enumerate(expect):
+            assert got[m].tobytes() == level.tobytes(), f"{w}x{h} level {m}"
+    neg = np.full((4, 4), -1.0, np.float32)
+    got = oracle.build_hzb(neg, 6, 6, 2)
+    assert got[0].shape == (6, 6) and (got[0] == -1.0).all()      # copy, clamped at the source edge
+    assert (got[1] == 0.0).all()                                   # max(0, ...) from then on

@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_exchange_block_words", "vkrhip_exchange_result_words", "vkrhip_exchange_pack",
     "vkrhip_exchange_merge", "vkrhip_comm_unique_id", "vkrhip_comm_init", "vkrhip_exchange_configure",
-    "vkrhip_exchange_run", "vkrhip_exchange_finish", "vkrhip_candidate_epoch", "vkrhip_set_hzb", "vkrhip_read_transmission_candidates",
+    "vkrhip_exchange_run", "vkrhip_exchange_finish", "vkrhip_candidate_epoch", "vkrhip_set_hzb", "vkrhip_build_hzb", "vkrhip_read_hzb", "vkrhip_read_transmission_candidates",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize", "vkrhip_effective_visibility",
 ]
@@ -187,6 +187,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_exchange_run.argtypes = [vp]
     L.vkrhip_exchange_finish.argtypes = [vp, vp, vp, vp]
     L.vkrhip_set_hzb.argtypes = [vp, vp, u32, u32, u32, vp, C.c_float]
+    L.vkrhip_build_hzb.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.c_float]
+    L.vkrhip_read_hzb.argtypes = [vp, u32, vp]
     L.vkrhip_candidate_epoch.argtypes = [vp, vp, vp]
     L.vkrhip_read_transmission_candidates.argtypes = [vp, u64, u64, vp]
     L.vkrhip_exchange_block_words.argtypes = [u32, u32, u32]

@@ -250,6 +250,37 @@ __device__ __forceinline__ bool hzb_occluded(const CullArgs &a, float cx, float 
   return true;
 }
 
+// vk_hzb_build, deferred.slang:970-998. Level 0 copies the depth image (source
+// texel min(xy, source extent - 1)); every further level takes the maximum,
+// starting from 0, of the 2x2 source texels min(2 xy + {0,1}, source extent - 1).
+struct HzbBuildArgs {
+  const float *source;
+  float *destination;
+  uint32_t source_width, source_height;
+  uint32_t width, height;
+  uint32_t copy;  // level 0
+};
+__global__ __launch_bounds__(256) void k_hzb_build(HzbBuildArgs a) {
+  const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+  const uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
+  if (x >= a.width || y >= a.height) return;
+  float out;
+  if (a.copy) {
+    out = a.source[(uint64_t)min(y, a.source_height - 1u) * a.source_width + min(x, a.source_width - 1u)];
+  } else {
+    out = 0.0f;
+#pragma unroll
+    for (uint32_t dy = 0; dy < 2u; ++dy)
+#pragma unroll
+      for (uint32_t dx = 0; dx < 2u; ++dx) {
+        const uint32_t sx = min(x * 2u + dx, a.source_width - 1u);
+        const uint32_t sy = min(y * 2u + dy, a.source_height - 1u);
+        out = fmaxf(out, a.source[(uint64_t)sy * a.source_width + sx]);
+      }
+  }
+  a.destination[(uint64_t)y * a.width + x] = out;
+}
+
 // Classifies one candidate against every view. Must be called by all threads of
 // the wave (it votes). `valid` lanes own candidate i with model matrix m;
 // `round` is the candidate's 256-wide round inside its segment. Returns the

@@ -1611,6 +1611,71 @@ int vkrhip_set_hzb(vkrhip_ctx *c, const float *mips, uint32_t width, uint32_t he
   return VKRHIP_OK;
 }
 
+int vkrhip_build_hzb(vkrhip_ctx *c, const float *depth, uint32_t source_width,
+                     uint32_t source_height, uint32_t width, uint32_t height, uint32_t mip_count,
+                     const float *view_projection, float depth_epsilon) {
+  if (!c || !depth || !view_projection) return VKRHIP_ERR_ARG;
+  if (!source_width || !source_height || !width || !height || !mip_count || mip_count > 32)
+    return fail(c, VKRHIP_ERR_ARG, "empty depth image, empty pyramid or more than 32 levels");
+  TRY(bind_device(c));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint32_t offsets[32];
+  uint64_t texels = 0;
+  for (uint32_t m = 0; m < mip_count; ++m) {
+    offsets[m] = (uint32_t)texels;
+    texels += (uint64_t)std::max(width >> m, 1u) * std::max(height >> m, 1u);
+    if (texels > 0xffffffffull) return fail(c, VKRHIP_ERR_CAPACITY, "depth pyramid too large");
+  }
+  const uint64_t source_texels = (uint64_t)source_width * source_height;
+  DevBuf<float> d_depth;
+  TRY(dev_alloc(c, d_depth, source_texels));
+  int rc = dev_alloc(c, c->hzb, texels);
+  if (rc == VKRHIP_OK) rc = dev_alloc(c, c->hzb_offset, 32);
+  if (rc == VKRHIP_OK) rc = dev_alloc(c, c->hzb_view_projection, 4);
+  hipError_t e = hipSuccess;
+  if (rc == VKRHIP_OK) {
+    e = hipMemcpyAsync(d_depth.p, depth, source_texels * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(c->hzb_offset.p, offsets, mip_count * sizeof(uint32_t), hipMemcpyHostToDevice,
+                         c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(c->hzb_view_projection.p, view_projection, 64, hipMemcpyHostToDevice, c->stream);
+    for (uint32_t m = 0; m < mip_count && e == hipSuccess; ++m) {
+      HzbBuildArgs a{};
+      a.copy = m == 0 ? 1u : 0u;
+      a.source = m == 0 ? d_depth.p : c->hzb.p + offsets[m - 1];
+      a.source_width = m == 0 ? source_width : std::max(width >> (m - 1), 1u);
+      a.source_height = m == 0 ? source_height : std::max(height >> (m - 1), 1u);
+      a.width = std::max(width >> m, 1u);
+      a.height = std::max(height >> m, 1u);
+      a.destination = c->hzb.p + offsets[m];
+      hipLaunchKernelGGL(k_hzb_build, dim3((unsigned)ceil_div(a.width, 16), (unsigned)ceil_div(a.height, 16)),
+                         dim3(256), 0, c->stream, a);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `offsets` and the caller's arrays
+  }
+  dev_free(d_depth);
+  if (rc != VKRHIP_OK) return rc;
+  HIP_TRY(c, e);
+  c->hzb_width = width;
+  c->hzb_height = height;
+  c->hzb_mips = mip_count;
+  c->hzb_epsilon = depth_epsilon;
+  return VKRHIP_OK;
+}
+
+int vkrhip_read_hzb(vkrhip_ctx *c, uint32_t mip, float *out) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  if (mip >= c->hzb_mips) return fail(c, VKRHIP_ERR_ARG, "mip %u of %u", mip, c->hzb_mips);
+  TRY(bind_device(c));
+  uint64_t offset = 0;
+  for (uint32_t m = 0; m < mip; ++m)
+    offset += (uint64_t)std::max(c->hzb_width >> m, 1u) * std::max(c->hzb_height >> m, 1u);
+  const uint64_t texels = (uint64_t)std::max(c->hzb_width >> mip, 1u) * std::max(c->hzb_height >> mip, 1u);
+  return read_back(c, out, c->hzb.p + offset, texels * sizeof(float));
+}
+
 int vkrhip_candidate_epoch(vkrhip_ctx *c, uint64_t *out_hash, uint32_t *out_occluders) {
   if (!c || !out_hash) return VKRHIP_ERR_ARG;
   TRY(bind_device(c));

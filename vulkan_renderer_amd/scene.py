@@ -414,6 +414,22 @@ class HipScene:
         self._ok(self.lib.vkrhip_set_hzb(self.ctx, N.ptr(flat), width, height, len(mips), N.ptr(vp),
                                          depth_epsilon))
 
+    def build_hzb(self, depth, width: int, height: int, mip_count: int, view_projection,
+                  depth_epsilon: float = 0.0) -> None:
+        """Pyramid from a depth image (vk_hzb_build, deferred.slang:970-998), then as set_hzb."""
+        depth = N.as_f32(depth)
+        assert depth.ndim == 2
+        vp = N.as_f32(view_projection).reshape(16)
+        self._ok(self.lib.vkrhip_build_hzb(self.ctx, N.ptr(depth), depth.shape[1], depth.shape[0], width,
+                                           height, mip_count, N.ptr(vp), depth_epsilon))
+        self._hzb_extent = (width, height)
+
+    def read_hzb(self, mip: int) -> np.ndarray:
+        w, h = (max(e >> mip, 1) for e in self._hzb_extent)
+        out = np.empty((h, w), np.float32)
+        self._ok(self.lib.vkrhip_read_hzb(self.ctx, mip, N.ptr(out)))
+        return out
+
     def candidate_epoch(self):
         """(hash, occluder_count) of vkr_vk_candidate_epoch
         (lib/src/renderer/vulkan/vkr_vulkan_draws.c:19-44) for the current candidates
