@@ -49,14 +49,16 @@ WORKLOADS = {
 #   classify : world 64 + sphere 16 + flags 4 in; visibility byte 1 out, plus 4 per
 #              surviving (instance, view) (the staged survivor index)
 #   fused    : both, minus the re-read of world (it is classified in registers)
-def kernel_bytes(name: str, n: int, depth: int, survivors: int, dirty_local: bool = False) -> float:
+def kernel_bytes(name: str, n: int, depth: int, survivors: int, dirty_local: bool = False,
+                 submeshes: int = 1) -> float:
     transform = 64 + 64 + 2 + (4 if depth > 1 else 0)
     if dirty_local:  # TRS 48 in instead of the cached local, rebuilt local 64 out
         transform += 48
 
-    classify_in, classify_out = 64 + 16 + 4, 1
+    # with several rows per transform the matrix is fetched once per node
+    classify_in, classify_out = 64 / submeshes + 16 + 4 + (4 if submeshes > 1 else 0), 1
     if name == "transform":
-        return n * transform
+        return (n // submeshes) * transform
     if name == "classify":
         return n * (classify_in + classify_out) + 4 * survivors
     if name == "fused":
@@ -89,9 +91,9 @@ def pmc_traffic(workload_name: str, overridden: bool, kernel: str):
     return (total or None), os.path.relpath(paths[-1], ROOT)
 
 
-def build_scene(workload: dict, rank: int, seed: int):
+def build_scene(workload: dict, rank: int, seed: int, submeshes: int = 1):
     from vulkan_renderer_amd import synth
-    n = workload["n"]
+    n = workload["n"] // submeshes
     if workload["depth"] > 1:
         sc = synth.deep_scene(n, depth=workload["depth"], seed=seed + 1 + rank)
     else:
@@ -100,6 +102,11 @@ def build_scene(workload: dict, rank: int, seed: int):
     extra = None
     if workload["probes"]:
         extra, _ = synth.ring_views(workload["probes"])
+    if submeshes > 1:  # `submeshes` candidate rows per transform, in node order
+        rows = sc.n * submeshes
+        index = np.arange(rank * rows, (rank + 1) * rows, dtype=np.uint64)
+        sc.ident, sc.matbits, sc.bounds = synth.make_candidates(seed, index)
+        sc.node = (np.arange(rows, dtype=np.uint64) // np.uint64(submeshes)).astype(np.uint32)
     return sc, vs, extra
 
 
@@ -113,6 +120,9 @@ def main() -> int:
     ap.add_argument("--depth", type=int, default=-1, help="override hierarchy depth")
     ap.add_argument("--cascades", type=int, default=-1, help="override shadow cascade count")
     ap.add_argument("--probes", type=int, default=-1, help="override extra probe views")
+    ap.add_argument("--submeshes", type=int, default=1,
+                    help="candidate rows per transform (>1: the stand-alone transform and classify "
+                         "kernels run instead of the fused one)")
     ap.add_argument("--dirty", default="world", choices=["world", "local"],
                     help="what moves every frame: world = cached local matrices are re-propagated "
                          "(default); local = every node's TRS changed, locals are rebuilt too")
@@ -166,20 +176,21 @@ def main() -> int:
         if getattr(args, key) >= 0:
             workload[key] = getattr(args, key)
     n = workload["n"]
-    sc, vs, extra = build_scene(workload, rank, args.seed)
+    sc, vs, extra = build_scene(workload, rank, args.seed, args.submeshes)
+    n = sc.ident.shape[0]
     planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
     if extra is not None:
         planes = np.concatenate([planes, np.stack([frustum_from_matrix(m) for m in extra])])
         required = np.concatenate([required, np.full(len(extra), N.CAND_SHADOW_CASTER, np.uint32)])
     views = planes.shape[0]
 
-    hs = HipScene(max_nodes=sc.n, max_candidates=sc.n, max_views=views, device=local_rank,
+    hs = HipScene(max_nodes=sc.n, max_candidates=n, max_views=views, device=local_rank,
                   source_index_base=rank * n)
     stream = torch.cuda.current_stream()
     hs.set_stream(stream.cuda_stream)
     hs.set_hierarchy(sc.parent if workload["depth"] > 1 else None, sc.level_offsets)
     hs.upload_trs(sc.pos, sc.quat, sc.scale)
-    hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+    hs.set_candidates(sc.node if args.submeshes > 1 else None, sc.ident, sc.matbits, sc.bounds)
     hs.set_views(planes, required, vs.view)
     hs.frame(N.STAGE_TRANSFORM)  # materialise local matrices from TRS once (not timed)
     hs.sync()
@@ -263,9 +274,10 @@ def main() -> int:
     dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
     launches = 1 if dominant == "classify" else len(sc.level_offsets) - 1
     survivors = sum(st.visible_count for st in info.views) + info.transparent_draw_count
-    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors, args.dirty == "local")
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors, args.dirty == "local",
+                             args.submeshes)
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-    overridden = (bool(args.instances) or args.dirty != "world" or
+    overridden = (bool(args.instances) or args.dirty != "world" or args.submeshes != 1 or
                   any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes")))
     traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant])
     roofline = {
@@ -287,7 +299,7 @@ def main() -> int:
         "config": {
             "workload": f"{args.workload}: {workload['desc']}",
             "instances_per_gpu": n, "instances_total": total_instances, "views": views,
-            "hierarchy_depth": len(sc.level_offsets) - 1,
+            "hierarchy_depth": len(sc.level_offsets) - 1, "rows_per_transform": args.submeshes,
             "visible_camera": info.views[0].visible_count,
             "transparent_draws": info.transparent_draw_count,
             "moved_per_frame": "every node: " + ("TRS (locals rebuilt)" if args.dirty == "local"
