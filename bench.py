@@ -66,7 +66,7 @@ def kernel_bytes(name: str, n: int, depth: int, survivors: int, dirty_local: boo
     raise KeyError(name)
 
 
-KERNEL_NAMES = {"transform": "k_propagate_level", "classify": "k_classify",
+KERNEL_NAMES = {"transform": "k_propagate_classify", "classify": "k_classify",
                 "fused": "k_propagate_classify"}
 
 

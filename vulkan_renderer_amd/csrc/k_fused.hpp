@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t in_range_mask(uint32_t rel, uint32_t lo, uin
   return (rel >= lo && rel < hi) ? 0xffffffffu : 0u;
 }
 
-template <bool HAS_PARENT>
+template <bool HAS_PARENT, bool CULL>
 __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h) {
@@ -99,9 +99,13 @@ __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t ti
   const uint64_t i = tile_base + clamp_rel(rbase + t, lo, hi);
   h.p = NO_PARENT;
   if (HAS_PARENT) h.p = a.t.parent[i];
-  const uint64_t ci = min(i, a.c.n - 1u);
-  h.ls = a.c.sphere[ci];
-  h.cf = a.c.cflags[ci];
+  h.ls = make_float4(0.f, 0.f, 0.f, 0.f);
+  h.cf = 0u;
+  if (CULL) {
+    const uint64_t ci = min(i, a.c.n - 1u);
+    h.ls = a.c.sphere[ci];
+    h.cf = a.c.cflags[ci];
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     h.raw[r] = a.t.flags[tile_base + clamp_rel(rbase + sub_slot(r), lo, hi)];
@@ -174,13 +178,13 @@ __device__ __forceinline__ float4 local_col_from_quad(float4 piece, uint32_t col
   return local_col_from_trs(pos, quat, scale, col);
 }
 
-template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT>
+template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true>
 // Four waves per SIMD: a level of 1M nodes is exactly one resident set of blocks
 // (4 per CU), and the register budget of 128 lets the compiler keep the three
 // pipeline stages apart.
 __global__ __launch_bounds__(FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 k_propagate_classify(FusedArgs a) {
-  __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
+  __shared__ float4 s_mat[CULL ? FUSED_BLOCK * MAT_LDS_STRIDE : 1];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ uint32_t s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
   static_assert((F_DIRTY_LOCAL | F_DIRTY_WORLD | F_WORLD_UPDATED) < F_HAS_PARENT, "marker bit is free");
@@ -200,11 +204,12 @@ k_propagate_classify(FusedArgs a) {
   hi = min(hi, (first_round + a.rounds) * FUSED_BLOCK);
   const uint64_t seg = (uint64_t)a.seg_base + blockIdx.x;  // block order is candidate order
   if (lo >= hi) {  // block-uniform
-    segment_empty(a.c, seg);
+    if (CULL) segment_empty(a.c, seg);
     return;
   }
   if (t == 0) s_updated = 0u;
-  CullShared s = cull_shared_init(a.c.views);
+  CullShared s{};
+  if (CULL) s = cull_shared_init(a.c.views);
   uint32_t packed = 0u;  // per round: state bucket and blend-row visibility of this thread's candidate
 
   // rounds of the tile that overlap the level (block-uniform)
@@ -215,8 +220,8 @@ k_propagate_classify(FusedArgs a) {
   // round r+1 and the head of round r+2 are in flight.
   FusedHead head_next, head_after;
   FusedBody body_next;
-  if (active(0)) fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, 0u, head_next);
-  if (active(1)) fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
+  if (active(0)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, 0u, head_next);
+  if (active(1)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
   if (active(0)) {
     fused_resolve_head(a, tile_base, lo, hi, 0u, head_next);
     fused_issue_body(a, tile_base, lo, hi, 0u, head_next, body_next);
@@ -236,7 +241,7 @@ k_propagate_classify(FusedArgs a) {
       fused_issue_body(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
     if (active(round + 2))
-      fused_issue_head<HAS_PARENT>(a, tile_base, lo, hi, rbase + 2 * FUSED_BLOCK, head_after);
+      fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, rbase + 2 * FUSED_BLOCK, head_after);
     if (!active(round)) continue;
 
     // ---- transform phase -------------------------------------------------------
@@ -290,9 +295,10 @@ k_propagate_classify(FusedArgs a) {
       }
       if (did_update) a.t.world[node * 4u + col] = wcol;
       if (valid && col == 0) a.t.flags[node] = (uint8_t)fr;
-      s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
+      if (CULL) s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
       updated_here += (did_update && col == 0) ? 1u : 0u;  // per lane; summed when the block ends
     }
+    if (!CULL) continue;  // transform only
     __builtin_amdgcn_wave_barrier();  // the wave's own columns: LDS keeps a wave's accesses in order
 
     // ---- cull phase ------------------------------------------------------------
@@ -314,7 +320,10 @@ k_propagate_classify(FusedArgs a) {
     const uint32_t wave_updates = wave_inclusive_scan(updated_here);
     if ((t & 63u) == 63u && wave_updates) atomicAdd(&s_updated, wave_updates);
   }
-  segment_finish<TIES>(a.c, s, seg, tile_base + lo, lo, packed);
+  if (CULL)
+    segment_finish<TIES>(a.c, s, seg, tile_base + lo, lo, packed);
+  else
+    __syncthreads();  // s_updated is complete
   if (t == 0 && s_updated) atomicAdd(a.t.counters + stat_shard() + CNT_NODES_UPDATED, s_updated);
 }
 

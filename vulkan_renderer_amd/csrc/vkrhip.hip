@@ -942,19 +942,23 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   return a;
 }
 
+static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *rounds);
+
+// Transform only: the fused kernel without its cull phase.
 static int launch_transform(vkrhip_ctx *c) {
   bool first = true;
   const uint32_t levels = c->level_offsets.empty() ? 0u : (uint32_t)c->level_offsets.size() - 1u;
   for (uint32_t l = 0; l < levels; ++l) {
-    const TransformArgs a = transform_args(c, l);
-    if (a.end == a.begin) continue;
-    const unsigned grid = (unsigned)ceil_div(a.end - a.begin, TF_TILE);
+    FusedArgs a{};
+    const uint64_t grid = fused_level_grid(c, l, &a.rounds);
+    if (!grid) continue;
+    a.t = transform_args(c, l);
     if (l == 0 || !c->parent.p)
-      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_level<false>, dim3(grid),
-                   dim3(TF_BLOCK), 0, a);
+      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<false, false, false, false>,
+                   dim3((unsigned)grid), dim3(FUSED_BLOCK), 0, a);
     else
-      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_level<true>, dim3(grid),
-                   dim3(TF_BLOCK), 0, a);
+      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<true, false, false, false>,
+                   dim3((unsigned)grid), dim3(FUSED_BLOCK), 0, a);
     first = false;
   }
   c->force_flags = 0;
