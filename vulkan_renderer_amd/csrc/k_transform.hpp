@@ -35,16 +35,6 @@ struct TransformArgs {
   uint32_t force;  // flag bits OR-ed into every node first (bulk "everything moved")
 };
 
-__global__ __launch_bounds__(256) void k_local_from_trs(const float4 *pos, const float4 *quat,
-                                                        const float4 *scale, float4 *local,
-                                                        uint64_t begin, uint64_t end) {
-  const uint64_t lane = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  const uint64_t node = begin + (lane >> 2);
-  const uint32_t col = threadIdx.x & 3u;
-  if (node >= end) return;
-  local[node * 4u + col] = local_col_from_trs(pos[node], quat[node], scale[node], col);
-}
-
 __global__ __launch_bounds__(256) void k_or_flags(uint8_t *flags, uint64_t n, uint8_t bits) {
   // 16 flag bytes per thread
   const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
