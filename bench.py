@@ -8,8 +8,9 @@ already resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-Workloads (BASELINE.json configs): flat1m (config 2, default), deep16m
-(config 3), flat32m (config 4's per-GPU shard), probes64 (config 5 shape).
+Workloads: flat1m (1M instances, flat, one view; the default), deep16m (16M,
+depth-8 hierarchy, camera + 4 cascades), flat32m (the per-GPU shard of 256M over
+eight GPUs), probes64 (16M, 64 views).
 With N > 1 every rank owns a contiguous shard of the same size (weak scaling)
 and the per-frame exchange all-gathers the visible lists and merges the sorted
 draw-key runs.
@@ -44,7 +45,7 @@ WORKLOADS = {
                      desc="16M instances per GPU, flat hierarchy, 64 views"),
 }
 
-# Algorithmic HBM bytes per unit for each kernel of the frame (see DESIGN.md):
+# Algorithmic HBM bytes per unit for each kernel of the frame:
 #   transform: local 64 + parent index 4 (non-root) + flags 1+1 + world 64
 #   classify : world 64 + sphere 16 + flags 4 in; visibility byte 1 out, plus 4 per
 #              surviving (instance, view) (the staged survivor index)
