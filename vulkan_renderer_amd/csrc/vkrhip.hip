@@ -1851,7 +1851,13 @@ int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, u
                 c->comm ? c->comm_world : 1u);
   if (c->views == 0) return fail(c, VKRHIP_ERR_STATE, "no views set");
   TRY(bind_device(c));
-  if (!c->xstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+  if (!c->xstream) {
+    // its few small kernels sit between collectives: highest priority, so they are
+    // dispatched ahead of the next frame's large grids (and from a queue of their own)
+    int least = 0, greatest = 0;
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(c, hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, greatest));
+  }
   if (!c->x_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->x_packed, hipEventDisableTiming));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->xstream));
@@ -1879,7 +1885,9 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
   const int k = (int)(c->x_turn++ & 1u);
   auto &x = c->xset[k];
   // the exchange that used this set two frames ago must be done with it
-  if (x.in_flight) HIP_TRY(c, hipStreamWaitEvent(c->stream, x.done, 0));
+  // (normally long finished: a barrier packet is only queued when it is not)
+  if (x.in_flight && hipEventQuery(x.done) != hipSuccess)
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, x.done, 0));
   TRY(enqueue_exchange_pack(c, x.send.p, c->x_vis_cap, c->x_key_cap, c->x_packed));
   HIP_TRY(c, hipStreamWaitEvent(c->xstream, c->x_packed, 0));
   const uint64_t words = exchange_block_words(c->views, c->x_vis_cap, c->x_key_cap);
@@ -1889,7 +1897,10 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
       return fail(c, VKRHIP_ERR_HIP, "ncclAllGather failed: %s",
                   g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
   } else {
-    HIP_TRY(c, hipMemcpyAsync(x.recv.p, x.send.p, words * 4, hipMemcpyDeviceToDevice, c->xstream));
+    // block sizes are whole 16-byte units
+    hipLaunchKernelGGL(k_exchange_copy, dim3((unsigned)std::min<uint64_t>(ceil_div(words / 4, 256), 1024)),
+                       dim3(256), 0, c->xstream, reinterpret_cast<const uint4 *>(x.send.p),
+                       reinterpret_cast<uint4 *>(x.recv.p), words / 4);
   }
   TRY(enqueue_exchange_merge(c, x.recv.p, c->x_world, c->x_vis_cap, c->x_key_cap, x.merged_visible.p,
                              x.merged_keys.p, x.result.p, c->xstream, x.done));
