@@ -183,18 +183,21 @@ __device__ __forceinline__ uniform_ptr<float> as_uniform(const float4 *p) {
 // operation as its scalar form. The "+ 0" of the reference's dot product is
 // left out: adding +0 can only turn a -0 sum into +0, and the distance is only
 // compared against -radius, where the sign of a zero makes no difference.
+// `paired` holds the six planes two at a time, interleaved per component:
+// (nx, nx', ny, ny', nz, nz', d, d') for planes (0,1), (2,3), (4,5), so that
+// every packed operand is an aligned pair of consecutive scalars.
 typedef float float2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bool sphere_visible(uniform_ptr<float> planes, float cx, float cy,
+__device__ __forceinline__ bool sphere_visible(uniform_ptr<float> paired, float cx, float cy,
                                                float cz, float radius) {
   bool culled = false;
   const float neg_r = -radius;
   const float2v x = {cx, cx}, y = {cy, cy}, z = {cz, cz};
 #pragma unroll
-  for (int i = 0; i < 6; i += 2) {
-    const float2v nx = {planes[i * 4 + 0], planes[i * 4 + 4]};
-    const float2v ny = {planes[i * 4 + 1], planes[i * 4 + 5]};
-    const float2v nz = {planes[i * 4 + 2], planes[i * 4 + 6]};
-    const float2v d = {planes[i * 4 + 3], planes[i * 4 + 7]};
+  for (int j = 0; j < 3; ++j) {
+    const float2v nx = {paired[j * 8 + 0], paired[j * 8 + 1]};
+    const float2v ny = {paired[j * 8 + 2], paired[j * 8 + 3]};
+    const float2v nz = {paired[j * 8 + 4], paired[j * 8 + 5]};
+    const float2v d = {paired[j * 8 + 6], paired[j * 8 + 7]};
     const float2v dist = ((nx * x + ny * y) + nz * z) + d;
     culled = culled || (dist.x < neg_r) || (dist.y < neg_r);
   }

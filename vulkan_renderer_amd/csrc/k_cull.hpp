@@ -120,6 +120,7 @@ struct CullArgs {
   const float4 *sphere;    // local sphere per candidate
   const uint32_t *cflags;  // prepared word per candidate
   const float4 *planes;    // views x 6
+  const float4 *planes_paired;  // views x 6, planes 2j and 2j+1 interleaved per component
   const float *tie_eps;    // views x 6: eps * max(1,|d|)
   const uint32_t *required;
   const float4 *view;      // camera view matrix columns
@@ -303,9 +304,10 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   const bool blend_row = valid && (cf & CF_BLEND) && !(cf & CF_TRANSMISSIVE);
   bool tv = false;
   const uniform_ptr<float> planes = as_uniform(a.planes);
+  const uniform_ptr<float> paired = as_uniform(a.planes_paired);
   const uniform_ptr<float> tie_eps = as_uniform(a.tie_eps);
   const uniform_ptr<uint32_t> required = as_uniform(a.required);
-  if (blend_row) tv = bounds_valid ? sphere_visible(planes, c.x, c.y, c.z, radius) : true;
+  if (blend_row) tv = bounds_valid ? sphere_visible(paired, c.x, c.y, c.z, radius) : true;
   if (valid) a.tvis[i] = tv ? 1u : 0u;
   if (tv) {
     // application_transparent_depth + application_pack_transparent_sort_key,
@@ -350,7 +352,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     bool tie = false;
     if (pass && bounds_valid) {
       const uniform_ptr<float> vp = planes + v * 24u;
-      pass = sphere_visible(vp, c.x, c.y, c.z, radius);
+      pass = sphere_visible(paired + v * 24u, c.x, c.y, c.z, radius);
       if (TIES) {
 #pragma unroll
         for (int p = 0; p < 6; ++p) {

@@ -79,6 +79,7 @@ struct vkrhip_ctx {
   // views
   uint32_t views = 0;
   DevBuf<float4> planes;
+  DevBuf<float4> planes_paired;  // the same planes, two at a time (see sphere_visible)
   DevBuf<float> tie_eps;
   DevBuf<uint32_t> required;
   DevBuf<float4> camera_view;
@@ -433,6 +434,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->sphere, mc));
     TRY(dev_alloc(c, c->cflags, mc));
     TRY(dev_alloc(c, c->planes, VKRHIP_MAX_VIEWS * 6));
+    TRY(dev_alloc(c, c->planes_paired, VKRHIP_MAX_VIEWS * 6));
     TRY(dev_alloc(c, c->tie_eps, VKRHIP_MAX_VIEWS * 6));
     TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->camera_view, 4));
@@ -486,6 +488,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->sphere);
   dev_free(c->cflags);
   dev_free(c->planes);
+  dev_free(c->planes_paired);
   dev_free(c->tie_eps);
   dev_free(c->required);
   dev_free(c->camera_view);
@@ -767,7 +770,18 @@ int vkrhip_set_views(vkrhip_ctx *c, uint32_t views, const float *planes,
     const float d = std::fabs(planes[4 * k + 3]);
     eps[k] = c->cfg.tie_epsilon * (d > 1.0f ? d : 1.0f);
   }
+  // planes 2j and 2j+1 of a view interleaved component by component
+  // (nx, nx', ny, ny', nz, nz', d, d'): the operand pairs of the packed plane test
+  std::vector<float> paired((size_t)views * 24);
+  for (uint32_t v = 0; v < views; ++v)
+    for (uint32_t j = 0; j < 3; ++j)
+      for (uint32_t k = 0; k < 4; ++k) {
+        paired[v * 24 + j * 8 + k * 2 + 0] = planes[v * 24 + (2 * j) * 4 + k];
+        paired[v * 24 + j * 8 + k * 2 + 1] = planes[v * 24 + (2 * j + 1) * 4 + k];
+      }
   HIP_TRY(c, hipMemcpyAsync(c->planes.p, planes, (size_t)views * 96, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->planes_paired.p, paired.data(), (size_t)views * 96, hipMemcpyHostToDevice,
+                            c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->tie_eps.p, eps.data(), eps.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->required.p, required_flags, (size_t)views * 4, hipMemcpyHostToDevice,
                             c->stream));
@@ -916,6 +930,7 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.sphere = c->sphere.p;
   a.cflags = c->cflags.p;
   a.planes = c->planes.p;
+  a.planes_paired = c->planes_paired.p;
   a.tie_eps = c->tie_eps.p;
   a.required = c->required.p;
   a.view = c->camera_view.p;
