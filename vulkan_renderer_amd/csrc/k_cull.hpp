@@ -350,10 +350,14 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     const uint32_t req = required[v];
     bool pass = valid && bucket < 4u && !(cf & CF_UNPUBLISHED) && (cf & req) == req;
     bool tie = false;
-    if (pass && bounds_valid) {
+    // evaluated for the whole wave without a branch: the plane loads then issue
+    // together with the gate word, ahead of any wait
+    const bool inside = sphere_visible(paired + v * 24u, c.x, c.y, c.z, radius);
+    if (!TIES) pass = pass && (inside || !bounds_valid);
+    if (TIES && pass && bounds_valid) {
       const uniform_ptr<float> vp = planes + v * 24u;
-      pass = sphere_visible(paired + v * 24u, c.x, c.y, c.z, radius);
-      if (TIES) {
+      pass = inside;
+      {
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
           const float dist =
