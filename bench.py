@@ -71,7 +71,7 @@ KERNEL_NAMES = {"transform": "k_propagate_classify", "classify": "k_classify",
                 "fused": "k_propagate_classify"}
 
 
-def pmc_traffic(workload_name: str, overridden: bool, kernel: str):
+def pmc_traffic(workload_name: str, overridden: bool, kernel: str, variant=None):
     """HBM bytes per step of the dominant kernel from the committed rocprofv3
     counter passes of this workload (FETCH_SIZE doubled, the gfx950 correction
     for wide coalesced reads, plus WRITE_SIZE; tools/pmc_passes.sh collects them
@@ -86,7 +86,9 @@ def pmc_traffic(workload_name: str, overridden: bool, kernel: str):
         data = json.load(fh)
     total = 0.0
     for name, k in data["kernels"].items():
-        if name.startswith(kernel):
+        # the last template argument of k_propagate_classify tells the fused kernel
+        # (true) from its transform-only variant (false)
+        if name.startswith(kernel) and (variant is None or name.rstrip().endswith(variant + ">")):
             total += k["dispatches_per_frame"] * (k["fetch_bytes_per_dispatch_x2"] +
                                                   k["write_bytes_per_dispatch"])
     return (total or None), os.path.relpath(paths[-1], ROOT)
@@ -280,7 +282,8 @@ def main() -> int:
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     overridden = (bool(args.instances) or args.dirty != "world" or args.submeshes != 1 or
                   any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes")))
-    traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant])
+    traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant],
+                                          {"fused": "true", "transform": "false"}.get(dominant))
     roofline = {
         "bound": "hbm", "kernel": KERNEL_NAMES[dominant],
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
