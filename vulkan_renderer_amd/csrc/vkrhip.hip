@@ -302,6 +302,20 @@ void release_exchange(vkrhip_ctx *c) {
   c->xstream = nullptr;
 }
 
+// No exception leaves the library: a failed host allocation inside an entry point
+// becomes an error code like any other failure.
+int host_exception(vkrhip_ctx *c) {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    return fail(c, VKRHIP_ERR_CAPACITY, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(c, VKRHIP_ERR_STATE, "unexpected exception: %s", e.what());
+  } catch (...) {
+    return fail(c, VKRHIP_ERR_STATE, "unexpected exception");
+  }
+}
+
 // Timer scope: records an event pair around a stage when profiling is on.
 struct StageTimer {
   vkrhip_ctx *c;
@@ -570,7 +584,7 @@ int vkrhip_sync(vkrhip_ctx *c) {
 // scene state
 // ---------------------------------------------------------------------------
 int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes,
-                         const uint64_t *level_offsets, uint32_t levels) {
+                         const uint64_t *level_offsets, uint32_t levels) try {
   if (!c) return VKRHIP_ERR_ARG;
   if (n_nodes > c->cfg.max_nodes)
     return fail(c, VKRHIP_ERR_CAPACITY, "n_nodes %llu exceeds max_nodes %llu",
@@ -609,10 +623,12 @@ int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes
   c->n_nodes = n_nodes;
   c->level_offsets = lo;
   return VKRHIP_OK;
+} catch (...) {
+  return host_exception(c);
 }
 
 int vkrhip_upload_trs(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *pos4,
-                      const float *quat4, const float *scale4) {
+                      const float *quat4, const float *scale4) try {
   if (!c || !pos4 || !quat4 || !scale4) return c ? fail(c, VKRHIP_ERR_ARG, "null TRS array") : VKRHIP_ERR_ARG;
   TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_trs"));
   TRY(bind_device(c));
@@ -632,9 +648,11 @@ int vkrhip_upload_trs(vkrhip_ctx *c, uint64_t first, uint64_t count, const float
   HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
+} catch (...) {
+  return host_exception(c);
 }
 
-int vkrhip_upload_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *local16) {
+int vkrhip_upload_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *local16) try {
   if (!c || !local16) return c ? fail(c, VKRHIP_ERR_ARG, "null locals") : VKRHIP_ERR_ARG;
   TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_locals"));
   if (count == 0) return VKRHIP_OK;
@@ -648,6 +666,8 @@ int vkrhip_upload_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, const fl
   HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
+} catch (...) {
+  return host_exception(c);
 }
 
 int vkrhip_upload_worlds(vkrhip_ctx *c, uint64_t first, uint64_t count, const float *world16) {
@@ -682,7 +702,7 @@ int vkrhip_mark_all(vkrhip_ctx *c, uint8_t flags) {
 // candidates
 // ---------------------------------------------------------------------------
 int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const uint32_t *ident,
-                          const uint32_t *matbits, const float *bounds) {
+                          const uint32_t *matbits, const float *bounds) try {
   if (!c) return VKRHIP_ERR_ARG;
   if (n > c->cfg.max_candidates)
     return fail(c, VKRHIP_ERR_CAPACITY, "n %llu exceeds max_candidates %llu", (unsigned long long)n,
@@ -756,10 +776,12 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
     c->tcap = tcap;
   }
   return VKRHIP_OK;
+} catch (...) {
+  return host_exception(c);
 }
 
 int vkrhip_set_views(vkrhip_ctx *c, uint32_t views, const float *planes,
-                     const uint32_t *required_flags, const float *camera_view) {
+                     const uint32_t *required_flags, const float *camera_view) try {
   if (!c) return VKRHIP_ERR_ARG;
   if (views == 0 || views > c->cfg.max_views)
     return fail(c, VKRHIP_ERR_CAPACITY, "views %u outside 1..max_views %u", views, c->cfg.max_views);
@@ -789,6 +811,8 @@ int vkrhip_set_views(vkrhip_ctx *c, uint32_t views, const float *planes,
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->views = views;
   return VKRHIP_OK;
+} catch (...) {
+  return host_exception(c);
 }
 
 int vkrhip_set_publication(vkrhip_ctx *c, const vkrhip_geometry_entry *geometries,
@@ -1300,7 +1324,7 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
   return VKRHIP_OK;
 }
 
-int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) {
+int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
   if (!c || !out) return VKRHIP_ERR_ARG;
   if (!c->frame_ran) return fail(c, VKRHIP_ERR_STATE, "no frame has run");
   TRY(bind_device(c));
@@ -1345,6 +1369,8 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) {
     out->near_plane_ties[v] = 0;
   }
   return VKRHIP_OK;
+} catch (...) {
+  return host_exception(c);
 }
 
 int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
