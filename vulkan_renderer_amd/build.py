@@ -9,7 +9,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvkrhip.so")
 SOURCES = ["vkrhip.hip", "vkrhip_host.cpp"]
-HEADERS = ["device_math.hpp", "k_transform.hpp", "k_cull.hpp", "k_fused.hpp", "k_sort.hpp"]
+EXAMPLE_SRC = os.path.join(os.path.dirname(PKG_DIR), "examples", "scene_frame.c")
+EXAMPLE_BIN = os.path.join(PKG_DIR, "scene_frame")  # C host of the library (examples/scene_frame.c)
 
 # -ffp-contract=off: the reference fuses multiply-add only inside mat4_mul
 # (lib/src/math/mat.h:1145-1163); hipcc's default would fuse everywhere and
@@ -32,7 +33,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp"))]
     deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "vkr_hip_scene.h"))
     return any(os.path.getmtime(d) > built for d in deps)
 
@@ -45,7 +46,20 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    build_example(verbose)
     return LIB_PATH
+
+
+def build_example(verbose: bool = False) -> str:
+    """The plain C host (C11, gcc): proves the header is C and the library links
+    without anything else of this repository."""
+    include = os.path.join(os.path.dirname(PKG_DIR), "include")
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-I", include, "-o", EXAMPLE_BIN, EXAMPLE_SRC,
+           "-L", PKG_DIR, "-lvkrhip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EXAMPLE_BIN
 
 
 if __name__ == "__main__":
