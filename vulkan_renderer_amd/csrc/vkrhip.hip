@@ -174,7 +174,7 @@ struct vkrhip_ctx {
     hipEvent_t done = nullptr;
     bool in_flight = false;
   } xset[2];
-  uint32_t x_world = 0, x_vis_cap = 0, x_key_cap = 0, x_turn = 0;
+  uint32_t x_world = 0, x_views = 0, x_vis_cap = 0, x_key_cap = 0, x_turn = 0;
   int x_last = -1;
   // device-planned exchange
   DevBuf<uint64_t> exch_desc, exch_rank_view_start, exch_prefix, exch_runs;
@@ -1913,6 +1913,7 @@ int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, u
     x.in_flight = false;
   }
   c->x_world = world;
+  c->x_views = c->views;
   c->x_vis_cap = vis_cap;
   c->x_key_cap = key_cap;
   c->x_last = -1;
@@ -1922,6 +1923,9 @@ int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, u
 int vkrhip_exchange_run(vkrhip_ctx *c) {
   if (!c) return VKRHIP_ERR_ARG;
   if (!c->x_world) return fail(c, VKRHIP_ERR_STATE, "vkrhip_exchange_configure has not been called");
+  if (c->views != c->x_views)  // the block layout depends on the view count
+    return fail(c, VKRHIP_ERR_STATE, "view count changed from %u to %u: configure the exchange again",
+                c->x_views, c->views);
   TRY(bind_device(c));
   const int k = (int)(c->x_turn++ & 1u);
   auto &x = c->xset[k];
