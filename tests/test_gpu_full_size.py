@@ -1,0 +1,92 @@
+"""The benchmark configurations at their full single-GPU sizes, every output
+compared with the CPU oracle bit for bit (the oracle needs about ten seconds
+for the largest of them), plus the properties that hold at any size."""
+import numpy as np
+import pytest
+
+from helpers import DIRTY_WORLD, compare_frame, hip_scene_for, oracle_frame, view_set
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth():
+    from vulkan_renderer_amd import synth
+    return synth
+
+
+def _check_lists(hs, info, n):
+    """Size-independent properties of the per-view lists and the sorted draws."""
+    _, cf = hs.read_candidate_prep()
+    for v, st in enumerate(info.views):
+        vis = hs.read_visible(v, st.visible_count)
+        assert st.visible_count == int(st.bucket_counts.sum())
+        for b in range(4):
+            off, cnt = (int(x) for x in st.execution_ranges[b])
+            seg = vis[off:off + cnt]
+            assert (np.diff(seg.astype(np.int64)) > 0).all(), f"view {v} bucket {b} not ascending"
+            assert (((cf[seg] >> 4) & 0xF) == b).all(), f"view {v} bucket {b} holds other buckets"
+    t = info.transparent_draw_count
+    draws, _, keys, src = hs.read_transparent(t)
+    assert (keys[:-1] > keys[1:]).all(), "keys strictly descending"
+    tv = hs.read_transparent_visible()
+    assert t == int(tv.sum()) and (np.sort(src) == np.flatnonzero(tv)).all()
+    assert (draws["first_instance"] == np.arange(t)).all()
+    assert ((keys & np.uint64(0xFFFFFFFF)) == src.astype(np.uint64) + np.uint64(1)).all()
+
+
+def test_config2_one_million_flat(oracle):
+    """1M instances, flat hierarchy, one view."""
+    synth = _synth()
+    sc = synth.flat_scene(1 << 20, seed=1)
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        assert info.views[0].visible_count > 10000 and info.transparent_draw_count > 1000
+        _check_lists(hs, info, sc.n)
+        # the steady state of the benchmark: every node marked moved, same result
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame()
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert hs.frame_info().nodes_updated == sc.n
+
+
+def test_config3_sixteen_million_depth8_five_views(oracle):
+    """16M instances, depth-8 hierarchy, camera + 4 shadow cascades."""
+    synth = _synth()
+    sc = synth.deep_scene(1 << 24, depth=8, seed=3)
+    assert len(sc.level_offsets) == 9 and sc.n == 1 << 24
+    vs = synth.camera_views(cascades=4)
+    planes, required = view_set(vs)
+    assert planes.shape[0] == 5
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 5) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        assert info.transparent_draw_count > 8192  # the multi-pass sort
+        assert min(st.visible_count for st in info.views) > 10000
+        _check_lists(hs, info, sc.n)
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame()
+        compare_frame(hs, ref, sc, check_transform=False)
+
+
+def test_config5_slice_sixty_four_views(oracle):
+    """A 2M-instance slice of the 64-view probe configuration."""
+    synth = _synth()
+    sc = synth.flat_scene(1 << 21, seed=5)
+    vps, _ = synth.ring_views(63)
+    vs = synth.camera_views()
+    planes, required = view_set(vs, extra_vp=vps)
+    assert planes.shape[0] == 64
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, 64) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        assert sum(st.visible_count for st in info.views) > 100000
+        _check_lists(hs, info, sc.n)
