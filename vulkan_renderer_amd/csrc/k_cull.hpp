@@ -154,14 +154,14 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 //   mask  [CULL_SLOTS][views]   lanes of the slot that survive the view (ballot)
 //   inb   [CULL_SLOTS][4]       lanes of the slot per state bucket
 //   tmask [CULL_SLOTS]          lanes of the slot that are visible blend rows
-//   cnt   [CULL_SLOTS][rows]    filled when the segment ends: start position of the
+//   cnt   [CULL_SLOTS][rows]    (16-bit) filled when the segment ends: start position of the
 //                               slot's survivors of a row inside the segment
 //   ties  [views], stat [5]
 struct CullShared {
   unsigned long long *mask;
   unsigned long long *inb;
   unsigned long long *tmask;
-  uint32_t *cnt;
+  uint16_t *cnt;  // positions inside a segment: at most CULL_TILE
   uint32_t *ties;
   uint32_t *stat;
   uint32_t rows;
@@ -170,7 +170,8 @@ struct CullShared {
 
 __host__ __device__ inline size_t cull_shared_words(uint32_t views) {
   const uint32_t rows = views * 4u + 1u;
-  return 2u * ((size_t)CULL_SLOTS * views + CULL_SLOTS * 4u + CULL_SLOTS) + (size_t)CULL_SLOTS * rows +
+  static_assert(CULL_SLOTS % 2 == 0 && CULL_TILE < 65536, "16-bit positions, two to a word");
+  return 2u * ((size_t)CULL_SLOTS * views + CULL_SLOTS * 4u + CULL_SLOTS) + (size_t)(CULL_SLOTS / 2) * rows +
          views + 5u;
 }
 __host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
@@ -186,8 +187,8 @@ __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
   s.mask = cull_lds64;
   s.inb = s.mask + CULL_SLOTS * views;
   s.tmask = s.inb + CULL_SLOTS * 4u;
-  s.cnt = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
-  s.ties = s.cnt + CULL_SLOTS * s.rows;
+  s.cnt = reinterpret_cast<uint16_t *>(s.tmask + CULL_SLOTS);
+  s.ties = reinterpret_cast<uint32_t *>(s.cnt + CULL_SLOTS * s.rows);
   s.stat = s.ties + views;
   // everything starts at zero: slots a block does not run must read as "nobody survives"
   const uint32_t total = (uint32_t)cull_shared_words(views);
@@ -346,13 +347,24 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     const unsigned long long in_bucket = __ballot(bucket == q);
     if (leader) s.inb[slot * 4u + q] = in_bucket;
   }
+  const bool gate = valid && bucket < 4u && !(cf & CF_UNPUBLISHED);
+  // the view-independent part of the outcome as wave masks: what is left per view
+  // are two compares whose results are masks already
+  const unsigned long long gate_mask = __ballot(gate);
+  const unsigned long long unbounded_mask = __ballot(!bounds_valid);
   for (uint32_t v = 0; v < a.views; ++v) {
     const uint32_t req = required[v];
-    bool pass = valid && bucket < 4u && !(cf & CF_UNPUBLISHED) && (cf & req) == req;
-    bool tie = false;
     // evaluated for the whole wave without a branch: the plane loads then issue
     // together with the gate word, ahead of any wait
     const bool inside = sphere_visible(paired + v * 24u, c.x, c.y, c.z, radius);
+    if (!TIES && !HZB) {
+      const unsigned long long mp =
+          gate_mask & __ballot((cf & req) == req) & (__ballot(inside) | unbounded_mask);
+      if (leader) s.mask[slot * a.views + v] = mp;
+      continue;
+    }
+    bool pass = gate && (cf & req) == req;
+    bool tie = false;
     if (!TIES) pass = pass && (inside || !bounds_valid);
     if (TIES && pass && bounds_valid) {
       const uniform_ptr<float> vp = planes + v * 24u;
@@ -421,7 +433,7 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     const uint32_t b = lane >> 4;  // bucket of the row inside its view
     const uint32_t bucket_start = (b > 0u ? t0 : 0u) + (b > 1u ? t1 : 0u) + (b > 2u ? t2 : 0u);
     if (live) {
-      s.cnt[slot * s.rows + r] = bucket_start + incl - c;
+      s.cnt[slot * s.rows + r] = (uint16_t)(bucket_start + incl - c);
       if (slot == CULL_SLOTS - 1u) a.seg_counts[(uint64_t)r * a.seg_stride + seg] = incl;
     }
   }
@@ -434,7 +446,7 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     const bool tv = ((packed >> (8u * round)) & 0x10u) != 0u;
     const uint32_t rel = round * CULL_BLOCK + t - tile_to_first;  // candidate index - first
     const uint32_t slot = round * (CULL_BLOCK / 64u) + wave;
-    const uint32_t *start = s.cnt + slot * s.rows;
+    const uint16_t *start = s.cnt + slot * s.rows;
     // lower lanes holding this lane's bucket
     const unsigned long long below_same_bucket = bucket < 4u ? s.inb[slot * 4u + bucket] & lt_mask : 0ull;
     for (uint32_t v = 0; v < a.views; ++v) {
