@@ -111,13 +111,13 @@ def _shard_scene(rank, n):
     return sc
 
 
-@pytest.mark.parametrize("world,cascades", [(2, 2), (3, 0)])
-def test_device_planned_exchange(oracle, world, cascades):
+# the last case is the shape of an eight-GPU run of the benchmark: 1M instances per shard
+@pytest.mark.parametrize("world,cascades,n", [(2, 2, 30000), (3, 0, 30000), (8, 0, 1 << 20)])
+def test_device_planned_exchange(oracle, world, cascades, n):
     import torch
     from helpers import numpy_exchange_merge, numpy_exchange_pack, oracle_frame, view_set
     from vulkan_renderer_amd import HipScene, synth
     from vulkan_renderer_amd.parallel import exchange_block_words, exchange_result_words
-    n = 30000
     vs = synth.camera_views(cascades=cascades)
     planes, required = view_set(vs)
     v = planes.shape[0]
