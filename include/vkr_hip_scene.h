@@ -404,7 +404,7 @@ uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
  * vkrhip_exchange_run enqueues the pack on the context's stream and the
  * all-gather and the merge on a second stream, into one of two buffer sets: the
  * next vkrhip_frame may be enqueued at once and overlaps them. Without a
- * communicator (world 1) the all-gather is a device copy. vkrhip_exchange_finish
+ * communicator (world 1) the merge reads the packed block itself. vkrhip_exchange_finish
  * waits for the latest run and copies its result words (layout above,
  * vkrhip_exchange_result_words(views) of them); when result[0] has flag 1 or 2 a
  * rank did not fit: every rank sees the same flags and sizes, so all call

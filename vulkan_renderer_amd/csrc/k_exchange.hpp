@@ -95,12 +95,6 @@ __global__ __launch_bounds__(256) void k_exchange_pack(ExchangePackArgs a) {
   for (uint64_t i = first; i < n; i += step) dst[i] = a.keys[i];
 }
 
-// One rank and no communicator: the "all-gather" is a copy of the block.
-__global__ __launch_bounds__(256) void k_exchange_copy(const uint4 *src, uint4 *dst, uint64_t quads) {
-  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < quads; i += (uint64_t)gridDim.x * 256u)
-    dst[i] = src[i];
-}
-
 struct ExchangePlanArgs {
   const uint32_t *gathered;  // world blocks
   uint64_t *desc;            // [views*4][world] x {src word, dst word, count}

@@ -1941,14 +1941,10 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
     if (rc != 0)
       return fail(c, VKRHIP_ERR_HIP, "ncclAllGather failed: %s",
                   g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
-  } else {
-    // block sizes are whole 16-byte units
-    hipLaunchKernelGGL(k_exchange_copy, dim3((unsigned)std::min<uint64_t>(ceil_div(words / 4, 256), 1024)),
-                       dim3(256), 0, c->xstream, reinterpret_cast<const uint4 *>(x.send.p),
-                       reinterpret_cast<uint4 *>(x.recv.p), words / 4);
   }
-  TRY(enqueue_exchange_merge(c, x.recv.p, c->x_world, c->x_vis_cap, c->x_key_cap, x.merged_visible.p,
-                             x.merged_keys.p, x.result.p, c->xstream, x.done));
+  // without a communicator the world is this rank: its own block is the gathered buffer
+  TRY(enqueue_exchange_merge(c, c->comm ? x.recv.p : x.send.p, c->x_world, c->x_vis_cap, c->x_key_cap,
+                             x.merged_visible.p, x.merged_keys.p, x.result.p, c->xstream, x.done));
   x.in_flight = true;
   c->x_last = k;
   return VKRHIP_OK;

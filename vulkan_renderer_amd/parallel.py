@@ -322,8 +322,8 @@ class RcclExchange:
     library's two streams, so the host spends a few launches per frame instead of
     a Python collective. torch.distributed is only used once, to hand rank 0's
     RCCL unique id to the other ranks. Same interface and the same capacity
-    protocol as ShardExchange; world 1 needs no process group (the all-gather is
-    a device copy)."""
+    protocol as ShardExchange; world 1 needs no process group (the merge reads
+    the rank's own block)."""
 
     def __init__(self, scene, world: int, rank: int, views: int, group=None, vis_cap: int = 4096,
                  key_cap: int = 1024):
