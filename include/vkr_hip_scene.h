@@ -190,6 +190,8 @@ int vkrhip_set_stream(vkrhip_ctx *ctx, void *hip_stream);
  * vkrhip_set_stream changed it), for callers that want to order their own work
  * (copies, collectives) with the context's. */
 void *vkrhip_get_stream(const vkrhip_ctx *ctx);
+/* Waits for everything the context has enqueued (vkr_renderer_submit_packet
+ * returns only after the payload was consumed, lib/src/renderer/vkr_render_packet.h:121-125). */
 int vkrhip_sync(vkrhip_ctx *ctx);
 
 /* ---- scene state: replaces the SceneTransform column walked by
@@ -205,6 +207,8 @@ int vkrhip_upload_trs(vkrhip_ctx *ctx, uint64_t first, uint64_t count, const flo
                       const float *quat4, const float *scale4);
 /* Cached local matrices (SceneTransform.local); marks the nodes DIRTY_WORLD. */
 int vkrhip_upload_locals(vkrhip_ctx *ctx, uint64_t first, uint64_t count, const float *local16);
+/* World matrices computed elsewhere (SceneTransform.world, vkr_scene_system.h:60-65), for
+ * frames that run the cull stages without the transform stage; marks nothing. */
 int vkrhip_upload_worlds(vkrhip_ctx *ctx, uint64_t first, uint64_t count, const float *world16);
 int vkrhip_upload_node_flags(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
                              const uint8_t *flags);
