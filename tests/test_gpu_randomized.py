@@ -3,6 +3,8 @@ through the CPU oracle: random sizes (tile edges included), depths, view
 counts, partition capacities, and per frame a random set of moved nodes (TRS
 changes, DIRTY_WORLD marks, or nothing). Every output is compared bit for bit
 after every frame."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +27,9 @@ def _frame_reference(oracle, sc, state, planes, required, vs, partition_capacity
                 visible=vis, ties=ties)
 
 
-@pytest.mark.parametrize("seed", range(12))
+# VKR_RANDOM_SEEDS widens the sweep for a soak run; seeds from 12 on also draw
+# probe views (up to 64 views in all)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_RANDOM_SEEDS", "16"))))
 def test_random_scene_over_frames(oracle, seed):
     from helpers import compare_frame, hip_scene_for, view_set
     from vulkan_renderer_amd import synth
@@ -43,7 +47,8 @@ def test_random_scene_over_frames(oracle, seed):
     n = sc.n
     cascades = int(rng.integers(0, 5))
     vs = synth.camera_views(cascades=cascades, far=float(rng.choice([300.0, 900.0])))
-    planes, required = view_set(vs)
+    probes = int(rng.choice([0, 0, 7, 20, 59])) if seed >= 12 else 0
+    planes, required = view_set(vs, extra_vp=synth.ring_views(probes)[0] if probes else None)
     capacity = int(rng.choice([0, 0, 64, 1000]))
     state = dict(local=None, world=None, flags=np.full(n, DIRTY_LOCAL, np.uint8), pos=sc.pos.copy())
     with hip_scene_for(sc, planes.shape[0], partition_capacity=capacity) as hs:
