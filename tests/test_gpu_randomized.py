@@ -76,3 +76,67 @@ def test_random_scene_over_frames(oracle, seed):
             ref = _frame_reference(oracle, sc, state, planes, required, vs, capacity)
             hs.frame()
             compare_frame(hs, ref, sc, partition_capacity=capacity)
+
+
+STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT, STAGE_CANDIDATES, STAGE_BOUNDS = 1, 2, 4, 8, 16
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_RANDOM_SEEDS", "16"))))
+def test_random_feature_mix(oracle, seed):
+    """Random combinations of what selects a kernel variant: identity or arbitrary
+    candidate->node mapping, tie counting on or off, world bounds written or not,
+    the candidate rows emitted or not, one frame call or the stages split over two,
+    a source index base, small and large transparent counts."""
+    from conftest import assert_bits_equal
+    from helpers import compare_frame, hip_scene_for, oracle_frame, view_set
+    from vulkan_renderer_amd import synth
+    rng = np.random.default_rng(50000 + seed)
+    depth = int(rng.integers(1, 6))
+    n = int(rng.choice([200, 1024, 1500, 5000, 12000, 40000]))
+    blend = float(rng.choice([0.1, 0.5, 1.0]))
+    if depth == 1:
+        sc = synth.flat_scene(n, seed=seed, blend_fraction=blend, no_bounds_fraction=0.02)
+    else:
+        sc = synth.deep_scene(n, depth=depth, seed=seed, fanout=int(rng.integers(2, 7)),
+                              roots=int(rng.integers(1, 5)), blend_fraction=blend, no_bounds_fraction=0.02)
+    sc.pos[:, :3] *= np.float32(rng.choice([0.1, 0.5, 1.0]))
+    if rng.uniform() < 0.4:   # several rows per transform, arbitrary order
+        n_cand = int(rng.integers(1, 3 * sc.n))
+        sc.node = rng.integers(0, sc.n, n_cand).astype(np.uint32)
+        sc.ident, sc.matbits, sc.bounds = synth.make_candidates(
+            seed + 7, np.arange(n_cand, dtype=np.uint64), blend_fraction=blend)
+    n_cand = sc.ident.shape[0]
+    tie_eps = float(rng.choice([0.0, 0.0, 1e-5, 1e-2]))
+    base = int(rng.choice([0, 0, 1 << 20]))
+    vs = synth.camera_views(cascades=int(rng.integers(0, 5)), far=float(rng.choice([300.0, 2000.0])),
+                            fov_deg=float(rng.choice([60.0, 110.0])))
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, tie_eps=tie_eps,
+                       index_base=base)
+    extra = (STAGE_CANDIDATES if rng.uniform() < 0.5 else 0) | (STAGE_BOUNDS if rng.uniform() < 0.5 else 0)
+    split = rng.uniform() < 0.3
+    with hip_scene_for(sc, planes.shape[0], tie_epsilon=tie_eps, source_index_base=base) as hs:
+        hs.set_views(planes, required, vs.view)
+        if split:
+            hs.frame(STAGE_TRANSFORM)
+            assert hs.frame_info().nodes_updated == sc.n
+            hs.frame(STAGE_CULL | STAGE_TRANSPARENT | extra)
+            compare_frame(hs, ref, sc, check_transform=False)
+            assert_bits_equal(hs.read_world(), ref["world"], "world matrices")
+        else:
+            hs.frame(STAGE_TRANSFORM | STAGE_CULL | STAGE_TRANSPARENT | extra)
+            compare_frame(hs, ref, sc)
+        if extra & STAGE_CANDIDATES:
+            assert hs.read_candidates().tobytes() == ref["payload"]["gpu_candidates"].tobytes()
+        if extra & STAGE_BOUNDS:
+            wb = hs.read_world_bounds()
+            node = sc.node if sc.node is not None else np.arange(n_cand, dtype=np.uint32)
+            pick = rng.integers(0, n_cand, 40)
+            exp = np.stack([oracle.instance_world_bounds(ref["world"][node[i]], sc.bounds[i, :3],
+                                                         ref["payload"]["gpu_candidates"][i]["sphere"][3])
+                            for i in pick])
+            assert_bits_equal(wb[pick], exp, "instance world bounds")
+        # a second frame with everything marked moved gives the same lists
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame(STAGE_TRANSFORM | STAGE_CULL | STAGE_TRANSPARENT)
+        compare_frame(hs, ref, sc, check_transform=False)
