@@ -15,12 +15,13 @@ def _run(oracle, sc, cascades, mips, w, h, eps, **scene_kw):
     vs = synth.camera_views(cascades=cascades, far=900.0)
     planes, required = view_set(vs)
     vp = mat4_mul(vs.projection, vs.view)
+    tie_eps = scene_kw.get("tie_epsilon", 0.0)
     oracle.set_hzb(mips, w, h, vp, eps)
     try:
-        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, tie_eps=tie_eps)
     finally:
         oracle.set_hzb(None)
-    plain = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    plain = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, tie_eps=tie_eps)
     with hip_scene_for(sc, planes.shape[0], **scene_kw) as hs:
         hs.set_views(planes, required, vs.view)
         hs.set_hzb(mips, w, h, vp, eps)
@@ -109,3 +110,32 @@ def test_pyramid_built_on_the_device(oracle, sw, sh, w, h, mips):
         hs.frame()
         info = compare_frame(hs, ref, sc)
         assert info.views[0].occlusion_culled_count == int(ref["states"][0]["occlusion_culled_count"])
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VKR_RANDOM_SEEDS", "8"))))
+def test_random_pyramids(oracle, seed):
+    """Random extents, level counts, walls, epsilons and scene densities."""
+    from helpers import depth_pyramid
+    from vulkan_renderer_amd import synth
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+    walls = []
+    for _ in range(int(rng.integers(0, 6))):
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        walls.append((x0, y0, int(rng.integers(x0, w)) + 1, int(rng.integers(y0, h)) + 1,
+                      float(rng.choice([0.5, 0.9, 0.99, 0.999, 0.9999]))))
+    mips = depth_pyramid(w, h, walls, background=float(rng.choice([1.0, 0.9995])))
+    mips = mips[: int(rng.integers(1, len(mips) + 1))]
+    n = int(rng.choice([300, 5000, 30000]))
+    if rng.uniform() < 0.5:
+        sc = synth.flat_scene(n, seed=seed, blend_fraction=0.2, no_bounds_fraction=0.03)
+    else:
+        sc = synth.deep_scene(n, depth=int(rng.integers(2, 6)), seed=seed, fanout=4, roots=3,
+                              blend_fraction=0.2, no_bounds_fraction=0.03)
+    sc.pos[:, :3] *= np.float32(rng.choice([0.05, 0.3, 1.0]))
+    kw = {}
+    if rng.uniform() < 0.3:
+        kw["tie_epsilon"] = 1e-5
+    occluded, before, after = _run(oracle, sc, int(rng.integers(0, 3)), mips, w, h,
+                                   float(rng.choice([0.0, 1e-6, 1e-3])), **kw)
+    assert after == before - occluded
