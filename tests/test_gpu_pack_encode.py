@@ -35,14 +35,14 @@ def tables(sc, rng, drop_geometry=0.0, drop_material=0.0, stale_generation=0.0, 
     return geom, sub, mat
 
 
-def run_case(oracle, n, partition, **drops):
+def run_case(oracle, n, partition, scene_seed=6, cascades=2, spread=0.3, **drops):
     from helpers import hip_scene_for, view_set
     from oracle import pyoracle
     from vulkan_renderer_amd import synth
-    rng = np.random.default_rng(n + partition)
-    sc = synth.flat_scene(n, seed=6, blend_fraction=0.2)
-    sc.pos[:, :3] *= np.float32(0.3)
-    vs = synth.camera_views(cascades=2)
+    rng = np.random.default_rng(n + partition + 7919 * (scene_seed - 6))
+    sc = synth.flat_scene(n, seed=scene_seed, blend_fraction=0.2)
+    sc.pos[:, :3] *= np.float32(spread)
+    vs = synth.camera_views(cascades=cascades)
     planes, required = view_set(vs)
     views = planes.shape[0]
     geom, sub, mat = tables(sc, rng, **drops)
@@ -114,6 +114,16 @@ def test_partition_overflow_and_no_commands(oracle):
 def test_invalid_submesh_is_reported(oracle):
     info, counts = run_case(oracle, 4000, 4096, bad_submesh=40)
     assert counts[3] > 0 and info.invalid_submesh_count == counts[3]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VKR_RANDOM_SEEDS", "8"))))
+def test_random_publications(oracle, seed):
+    """Random sizes, partition capacities, view counts and publication gaps."""
+    rng = np.random.default_rng(31000 + seed)
+    run_case(oracle, int(rng.choice([1, 64, 1025, 3000, 20000])), int(rng.choice([0, 16, 700, 1 << 15])),
+             scene_seed=100 + seed, cascades=int(rng.integers(0, 5)), spread=float(rng.choice([0.1, 0.4, 1.0])),
+             drop_geometry=float(rng.choice([0.0, 0.1, 0.9])), drop_material=float(rng.choice([0.0, 0.2])),
+             stale_generation=float(rng.choice([0.0, 0.05])), bad_submesh=int(rng.choice([0, 0, 3])))
 
 
 def test_stages_need_a_publication(oracle):
