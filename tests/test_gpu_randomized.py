@@ -27,15 +27,15 @@ def _frame_reference(oracle, sc, state, planes, required, vs, partition_capacity
                 visible=vis, ties=ties)
 
 
-# VKR_RANDOM_SEEDS widens the sweep for a soak run; seeds from 12 on also draw
-# probe views (up to 64 views in all)
+# VKR_RANDOM_SEEDS widens the sweep for a soak run and VKR_RANDOM_SCALE multiplies the
+# scene sizes; seeds from 12 on also draw probe views (up to 64 views in all)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_RANDOM_SEEDS", "16"))))
 def test_random_scene_over_frames(oracle, seed):
     from helpers import compare_frame, hip_scene_for, view_set
     from vulkan_renderer_amd import synth
     rng = np.random.default_rng(1000 + seed)
     depth = int(rng.integers(1, 7))
-    n = int(rng.choice([1, 63, 255, 256, 257, 1023, 1024, 1025, 3000, 9000, 20000]))
+    n = int(rng.choice([1, 63, 255, 256, 257, 1023, 1024, 1025, 3000, 9000, 20000])) * int(os.environ.get("VKR_RANDOM_SCALE", "1"))
     if depth == 1:
         sc = synth.flat_scene(n, seed=seed, blend_fraction=0.25, transmissive_fraction=0.05,
                               no_bounds_fraction=0.03)
@@ -92,7 +92,7 @@ def test_random_feature_mix(oracle, seed):
     from vulkan_renderer_amd import synth
     rng = np.random.default_rng(50000 + seed)
     depth = int(rng.integers(1, 6))
-    n = int(rng.choice([200, 1024, 1500, 5000, 12000, 40000]))
+    n = int(rng.choice([200, 1024, 1500, 5000, 12000, 40000])) * int(os.environ.get("VKR_RANDOM_SCALE", "1"))
     blend = float(rng.choice([0.1, 0.5, 1.0]))
     if depth == 1:
         sc = synth.flat_scene(n, seed=seed, blend_fraction=blend, no_bounds_fraction=0.02)
