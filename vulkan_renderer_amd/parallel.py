@@ -259,6 +259,15 @@ class ShardExchange:
                 self._sets.append(b)
         if self.overlapped:
             self.source.synchronize()  # the fills above ran on the exchange stream
+        # gloo moves host memory: device blocks are staged through pinned buffers here
+        # (its own staging of device tensors stalled after a few frames without a host
+        # wait in between)
+        dist = torch.distributed
+        self._host_staged = (self._sets[0].send.is_cuda and dist.is_available() and dist.is_initialized()
+                             and dist.get_backend(self.group) == "gloo")
+        if self._host_staged:
+            self._host_send = torch.zeros(words, dtype=torch.int32).pin_memory()
+            self._host_recv = torch.zeros(self.world * words, dtype=torch.int32).pin_memory()
         self._last = None
 
     def run(self):
@@ -276,6 +285,11 @@ class ShardExchange:
         with self._exchange_scope():
             if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
                 b.recv.copy_(b.send, non_blocking=True)
+            elif self._host_staged:
+                self._host_send.copy_(b.send, non_blocking=True)
+                self.torch.cuda.current_stream().synchronize()
+                dist.all_gather_into_tensor(self._host_recv, self._host_send, group=self.group)
+                b.recv.copy_(self._host_recv, non_blocking=True)
             else:
                 dist.all_gather_into_tensor(b.recv, b.send, group=self.group)
             src.merge(b.recv, self.world, self.vis_cap, self.key_cap, b.vis_merged, b.key_merged,
