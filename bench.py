@@ -318,7 +318,9 @@ def main() -> int:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sc, planes, required, vs, args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)  # out before any teardown
+    if world > 1:
+        dist.barrier()  # no rank tears its communicator down while another still uses it
     hs.close()
     if world > 1:
         dist.destroy_process_group()
