@@ -14,16 +14,17 @@ def _synth():
     return synth
 
 
-def _check_lists(hs, info, n):
-    """Size-independent properties of the per-view lists and the sorted draws."""
+def _check_lists(hs, info, n, base=0):
+    """Size-independent properties of the per-view lists and the sorted draws
+    (`base` = the context's source index base: the lists hold global numbers)."""
     _, cf = hs.read_candidate_prep()
     for v, st in enumerate(info.views):
         vis = hs.read_visible(v, st.visible_count)
         assert st.visible_count == int(st.bucket_counts.sum())
         for b in range(4):
             off, cnt = (int(x) for x in st.execution_ranges[b])
-            seg = vis[off:off + cnt]
-            assert (np.diff(seg.astype(np.int64)) > 0).all(), f"view {v} bucket {b} not ascending"
+            seg = vis[off:off + cnt].astype(np.int64) - base
+            assert (np.diff(seg) > 0).all(), f"view {v} bucket {b} not ascending"
             assert (((cf[seg] >> 4) & 0xF) == b).all(), f"view {v} bucket {b} holds other buckets"
     t = info.transparent_draw_count
     draws, _, keys, src = hs.read_transparent(t)
@@ -31,7 +32,7 @@ def _check_lists(hs, info, n):
     tv = hs.read_transparent_visible()
     assert t == int(tv.sum()) and (np.sort(src) == np.flatnonzero(tv)).all()
     assert (draws["first_instance"] == np.arange(t)).all()
-    assert ((keys & np.uint64(0xFFFFFFFF)) == src.astype(np.uint64) + np.uint64(1)).all()
+    assert ((keys & np.uint64(0xFFFFFFFF)) == src.astype(np.uint64) + np.uint64(base + 1)).all()
 
 
 def test_config2_one_million_flat(oracle):
@@ -92,3 +93,20 @@ def test_config5_sixteen_million_sixty_four_views(oracle):
         info = compare_frame(hs, ref, sc)
         assert sum(st.visible_count for st in info.views) > 100000
         _check_lists(hs, info, sc.n)
+
+
+def test_config4_shard_thirty_two_million_flat(oracle):
+    """One GPU's shard of the 256M-instance configuration: 32M instances, flat, one
+    view, numbered as rank 3 of 8 numbers them."""
+    synth = _synth()
+    n = 1 << 25
+    sc = synth.flat_scene(n, seed=1, first=3 * n)
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, index_base=3 * n)
+    with hip_scene_for(sc, 1, source_index_base=3 * n) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        info = compare_frame(hs, ref, sc)
+        assert info.transparent_draw_count > 8192 and info.views[0].visible_count > 500000
+        _check_lists(hs, info, sc.n, base=3 * n)
