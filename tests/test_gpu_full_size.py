@@ -98,8 +98,9 @@ def test_config5_sixteen_million_sixty_four_views(oracle):
 def test_config4_shard_thirty_two_million_flat(oracle):
     """One GPU's shard of the 256M-instance configuration: 32M instances, flat, one
     view, numbered as rank 3 of 8 numbers them."""
+    import os
     synth = _synth()
-    n = 1 << 25
+    n = int(os.environ.get("VKR_CONFIG4_INSTANCES", 1 << 25))   # 1 << 27: the largest run of bench.py
     sc = synth.flat_scene(n, seed=1, first=3 * n)
     vs = synth.camera_views()
     planes, required = view_set(vs)
