@@ -354,9 +354,52 @@ def cpu_baseline(sc, planes, required, vs, budget_s: float) -> dict:
         if dt >= budget_s or frames >= 2000:
             break
     o.baseline_destroy(h)
-    return {"value": sample * frames / dt, "unit": "instances/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} frames of the first {sample} instances of the workload, "
-                      f"all {planes.shape[0]} views, {dt:.1f} s"}
+    out = {"value": sample * frames / dt, "unit": "instances/s", "cores": 1, "kind": "port",
+           "sample": f"{frames} frames of the first {sample} instances of the workload, "
+                     f"all {planes.shape[0]} views, {dt:.1f} s"}
+    if flat:
+        out["all_cores"] = cpu_baseline_all_cores(o, sc, sample, local, planes, required, vs,
+                                                  min(10.0, budget_s))
+    return out
+
+
+def cpu_baseline_all_cores(o, sc, sample, local, planes, required, vs, budget_s: float) -> dict:
+    """Not in the reference (its path runs on the render thread alone): the same
+    single-thread loop on every host core of this GPU's share at once, each thread
+    with its own copy of the sample and no merge of the results - an upper bound
+    for a sharded CPU version. The foreign calls release the interpreter lock."""
+    import threading
+    threads = max(1, min(16, os.cpu_count() or 1))
+    frames = [0] * threads
+    handles = [None] * threads
+    start = threading.Barrier(threads + 1)
+    stop_at = [0.0]
+
+    def work(k):
+        handles[k] = o.baseline_create(sc.parent[:sample], local, None, sc.ident[:sample],
+                                       sc.matbits[:sample], sc.bounds[:sample], planes, required,
+                                       vs.view, vs.projection)
+        o.baseline_frame(handles[k])  # warm
+        start.wait()
+        while time.perf_counter() < stop_at[0]:
+            o.baseline_frame(handles[k])
+            frames[k] += 1
+
+    pool = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    for t in pool:
+        t.start()
+    stop_at[0] = float("inf")
+    start.wait()
+    t0 = time.perf_counter()
+    stop_at[0] = t0 + budget_s
+    for t in pool:
+        t.join()
+    dt = time.perf_counter() - t0
+    for h in handles:
+        o.baseline_destroy(h)
+    return {"value": sample * sum(frames) / dt, "unit": "instances/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} threads, each looping over its own copy of the same {sample} "
+                      f"instances, no merge, {dt:.1f} s; not in the reference"}
 
 
 if __name__ == "__main__":
