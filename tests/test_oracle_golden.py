@@ -303,3 +303,17 @@ def test_hzb_build_matches_a_numpy_statement(oracle):
     got = oracle.build_hzb(neg, 6, 6, 2)
     assert got[0].shape == (6, 6) and (got[0] == -1.0).all()      # copy, clamped at the source edge
     assert (got[1] == 0.0).all()                                   # max(0, ...) from then on
+
+
+def test_bench_cpu_baseline_legs():
+    """The benchmark's CPU legs (one core, and the same loop on several cores at
+    once) on a small flat scene: both report a rate and say what was sampled."""
+    import bench
+    from vulkan_renderer_amd import build_view_set, synth
+    sc = synth.flat_scene(4096, seed=1)
+    vs = synth.camera_views()
+    planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
+    out = bench.cpu_baseline(sc, planes, required, vs, 0.3)
+    assert out["cores"] == 1 and out["kind"] == "port" and out["value"] > 0
+    many = out["all_cores"]
+    assert many["cores"] >= 1 and many["value"] > 0 and "not in the reference" in many["sample"]
