@@ -95,6 +95,26 @@ def compare_frame(hs, ref, sc, check_transform=True, partition_capacity=0):
     return info
 
 
+def clamp_to_list_capacity(states, visible, capacity):
+    """What a per-view list capacity below the survivor count leaves of the oracle's
+    (list-unlimited) result: every bucket keeps what still fits behind the buckets
+    before it, the rest is counted as overflow. The reference sizes the list for
+    every candidate (deferred.slang:400-403), so this knob is the library's own."""
+    states = states.copy()
+    out = np.full_like(visible, 0xFFFFFFFF)
+    for v in range(states.shape[0]):
+        cursor = 0
+        for b in range(4):
+            off, cnt = (int(x) for x in states[v]["execution_ranges"][b])
+            kept = min(cnt, max(capacity - cursor, 0))
+            out[v, cursor: cursor + kept] = visible[v, off: off + kept]
+            states[v]["execution_ranges"][b] = (cursor, kept)
+            states[v]["overflow_count"] += cnt - kept
+            cursor += kept
+        states[v]["visible_count"] = cursor
+    return states, out
+
+
 def hs_index_base(hs):
     return getattr(hs, "_index_base", 0)
 

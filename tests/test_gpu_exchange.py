@@ -373,3 +373,57 @@ def test_native_exchange_single_rank(oracle, with_comm):
             assert (ex.merged_ranges[vi] == st["execution_ranges"]).all()
             count, off = int(st["visible_count"]), int(ex.view_offsets[vi])
             assert (vis[off: off + count] == ref["visible"][vi, :count]).all()
+
+
+def test_exchange_refuses_a_publication(oracle):
+    """With a publication the visible lists hold rank-local packed row indices,
+    which cannot be concatenated across ranks: the exchange says so."""
+    import torch
+    from helpers import view_set
+    from test_gpu_pack_encode import tables
+    from vulkan_renderer_amd import HipScene, _native as N, synth
+    sc = synth.flat_scene(2000, seed=3)
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    geom, sub, mat = tables(sc, np.random.default_rng(1))
+    with HipScene(max_nodes=sc.n, max_candidates=sc.n, max_views=1) as hs:
+        hs.set_hierarchy(None, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+        hs.set_views(planes, required, vs.view)
+        hs.set_publication(geom, sub, mat)
+        hs.frame()
+        block = torch.zeros(hs.exchange_block_words(1, 4096, 512), dtype=torch.int32, device="cuda")
+        with pytest.raises(N.VkrHipError) as e:
+            hs.exchange_pack(block.data_ptr(), 4096, 512)
+        assert e.value.code == N.ERR_STATE
+
+
+def test_overflow_after_the_scene_advanced_is_not_repeated(oracle):
+    """finish() repeats an exchange whose blocks were too small by packing again;
+    once a newer frame has been enqueued that would carry the newer frame's lists,
+    so it raises with the sizes that would have fitted instead."""
+    from helpers import view_set
+    from vulkan_renderer_amd import HipScene, synth
+    from vulkan_renderer_amd.parallel import ExchangeOverflow, RcclExchange
+    n = 20000
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    sc = synth.flat_scene(n, seed=4, blend_fraction=0.3)
+    sc.pos[:, :3] *= np.float32(0.3)
+    with HipScene(max_nodes=n, max_candidates=n, max_views=1) as hs:
+        hs.set_hierarchy(None, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        hs.set_candidates(None, sc.ident, sc.matbits, sc.bounds)
+        hs.set_views(planes, required, vs.view)
+        ex = RcclExchange(hs, 1, 0, 1, vis_cap=64, key_cap=16)
+        hs.frame()
+        ex.run()
+        hs.mark_all(0x02)
+        hs.frame()          # frame k+1 is enqueued before frame k's exchange is finished
+        with pytest.raises(ExchangeOverflow) as e:
+            ex.finish()
+        assert e.value.need_visible > 64 and e.value.need_keys > 16
+        ex.run()            # the newer frame's own exchange sizes the blocks
+        ex.finish()
+        assert ex.regrown == 1

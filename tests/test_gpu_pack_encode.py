@@ -35,8 +35,8 @@ def tables(sc, rng, drop_geometry=0.0, drop_material=0.0, stale_generation=0.0, 
     return geom, sub, mat
 
 
-def run_case(oracle, n, partition, scene_seed=6, cascades=2, spread=0.3, **drops):
-    from helpers import hip_scene_for, view_set
+def run_case(oracle, n, partition, scene_seed=6, cascades=2, spread=0.3, list_capacity=0, **drops):
+    from helpers import clamp_to_list_capacity, hip_scene_for, view_set
     from oracle import pyoracle
     from vulkan_renderer_amd import synth
     rng = np.random.default_rng(n + partition + 7919 * (scene_seed - 6))
@@ -57,7 +57,10 @@ def run_case(oracle, n, partition, scene_seed=6, cascades=2, spread=0.3, **drops
     _, states, vis, _ = oracle.multiview_cull(packed_candidates, planes, required,
                                               partition_capacity=partition)
 
-    with hip_scene_for(sc, views, partition_capacity=partition) as hs:
+    if list_capacity:
+        states, vis = clamp_to_list_capacity(states, vis, list_capacity)
+
+    with hip_scene_for(sc, views, partition_capacity=partition, visible_capacity=list_capacity) as hs:
         hs.set_views(planes, required, vs.view)
         hs.set_publication(geom, sub, mat)
         hs.frame(STAGES)
@@ -109,6 +112,17 @@ def test_partition_overflow_and_no_commands(oracle):
     info, _ = run_case(oracle, 5000, 64, drop_geometry=0.05)
     assert any(st.overflow_count for st in info.views)
     run_case(oracle, 3000, 0, drop_material=0.2)       # unlimited partitions: no command buffer
+
+
+@pytest.mark.parametrize("list_capacity", [333, 1, 128, 1000])
+def test_list_capacity_below_the_survivors(oracle, list_capacity):
+    """A per-view list shorter than the survivors (and not a multiple of the encode
+    block): the ranges, counts, visible rows and commands all end at the capacity
+    and no view reads or writes its neighbour's stretch."""
+    info, _ = run_case(oracle, 20000, 4096, cascades=3, list_capacity=list_capacity)
+    assert max(st.visible_count for st in info.views) == list_capacity
+    assert any(st.overflow_count for st in info.views)
+    run_case(oracle, 6000, 0, cascades=1, list_capacity=list_capacity, drop_geometry=0.1)
 
 
 def test_invalid_submesh_is_reported(oracle):

@@ -343,3 +343,39 @@ def test_sort_path_misprediction(oracle):
         hs.set_views(p_n, r_n, narrow.view)
         hs.frame()                                   # predicted large, actually small
         compare_frame(hs, ref_n, sc, check_transform=False)
+
+
+def test_rows_must_name_nodes_of_the_scene(oracle):
+    """A row that names a node beyond the bound hierarchy is refused when it is
+    bound, and a hierarchy that shrinks under bound rows fails the frame."""
+    from vulkan_renderer_amd import _native as N
+    synth = _synth()
+    sc = synth.deep_scene(600, depth=4, seed=4, fanout=5, roots=3)
+    vs = synth.camera_views()
+    planes, required = view_set(vs)
+    n_cand = 900
+    ident, matbits, bounds = synth.make_candidates(3, np.arange(n_cand, dtype=np.uint64))
+    node = (np.arange(n_cand) % sc.n).astype(np.uint32)
+    sc.node, sc.ident, sc.matbits, sc.bounds = node, ident, matbits, bounds
+    from vulkan_renderer_amd import HipScene
+    with HipScene(max_nodes=2000, max_candidates=n_cand, max_views=1) as hs:
+        hs.set_hierarchy(sc.parent, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        bad = node.copy()
+        bad[17] = sc.n  # inside max_nodes, outside the hierarchy
+        with pytest.raises(N.VkrHipError) as e:
+            hs.set_candidates(bad, ident, matbits, bounds)
+        assert e.value.code == N.ERR_ARG
+        hs.set_candidates(node, ident, matbits, bounds)
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+        compare_frame(hs, ref, sc)
+        # the scene shrinks to its first two levels: the rows still name deeper nodes
+        small = int(sc.level_offsets[2])
+        hs.set_hierarchy(sc.parent[:small], sc.level_offsets[:3])
+        with pytest.raises(N.VkrHipError) as e:
+            hs.frame()
+        assert e.value.code == N.ERR_STATE
+        hs.set_candidates(node % small, ident, matbits, bounds)
+        hs.frame()

@@ -705,15 +705,27 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
 }
 
 // vk_gpu_draw_prefix (deferred.slang:354-377): the four bucket totals of a view
-// become execution ranges clamped to the partition capacity.
+// become execution ranges clamped to the partition capacity. The view's list
+// has a capacity of its own here (the reference sizes it for every candidate,
+// so it cannot run out there): a bucket keeps what still fits behind the
+// buckets before it, and what does not fit is counted in overflow_count like
+// the rows beyond a partition.
+__host__ __device__ __forceinline__ uint32_t bucket_room(uint32_t count, uint32_t partition_capacity,
+                                                         uint64_t list_capacity, uint32_t cursor) {
+  const uint32_t cap = partition_capacity ? partition_capacity : 0xffffffffu;
+  const uint32_t written = count < cap ? count : cap;
+  const uint64_t room = list_capacity > cursor ? list_capacity - cursor : 0u;
+  return (uint64_t)written < room ? written : (uint32_t)room;
+}
+
 __device__ __forceinline__ CompactionState prefix_state(const uint32_t *totals4,
-                                                        uint32_t partition_capacity) {
+                                                        uint32_t partition_capacity,
+                                                        uint64_t list_capacity) {
   CompactionState st;
   uint32_t cursor = 0, overflow = 0;
-  const uint32_t cap = partition_capacity ? partition_capacity : 0xffffffffu;
   for (uint32_t b = 0; b < 4u; ++b) {
     const uint32_t count = totals4[b];
-    const uint32_t written = count < cap ? count : cap;
+    const uint32_t written = bucket_room(count, partition_capacity, list_capacity, cursor);
     st.execution_ranges[b][0] = cursor;
     st.execution_ranges[b][1] = written;
     st.bucket_counts[b] = count;
@@ -769,10 +781,9 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
   const uint32_t wave = t >> 6;
   const uint32_t rows = a.views * 4u + 1u;
   const uint32_t vrows = a.views * 4u;
-  const uint32_t cap = a.partition_capacity ? a.partition_capacity : 0xffffffffu;
   if (blockIdx.x == 0)
     for (uint32_t v = t; v < a.views; v += GATHER_BLOCK)
-      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity);
+      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity, a.visible_stride);
 
   const uint64_t seg = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
   if (seg >= a.segments) return;  // wave-uniform; no block-wide barrier below
@@ -798,21 +809,21 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
       const uint32_t u = __shfl_up(cnt, d, 4);
       if ((lane & 3u) >= d) before += u;
     }
-    // output: start of the bucket inside the view's list, then the scanned offset
-    uint32_t range = 0u;
-    if (live && r < vrows)
-      for (uint32_t b = 0; b < (r & 3u); ++b) range += min(a.row_totals[(r & ~3u) + b], cap);
+    // output: start of the bucket inside the view's list (as prefix_state lays the
+    // buckets out), then the scanned offset
+    uint32_t range = 0u, kept = 0u;
+    if (live && r < vrows) {
+      for (uint32_t b = 0; b < (r & 3u); ++b)
+        range += bucket_room(a.row_totals[(r & ~3u) + b], a.partition_capacity, a.visible_stride, range);
+      kept = bucket_room(a.row_totals[r], a.partition_capacity, a.visible_stride, range);
+    }
     if (r == vrows) {  // the transparent row: copied with its keys below
       t_count = cnt;
       t_offset = off;
       cnt = 0u;
     } else if (live) {
       // entries beyond the partition capacity or the list capacity are dropped
-      const uint32_t room = off < cap ? cap - off : 0u;
-      cnt = min(cnt, room);
-      const uint64_t slot0 = (uint64_t)range + off;
-      const uint64_t list_room = slot0 < a.visible_stride ? a.visible_stride - slot0 : 0u;
-      cnt = (uint32_t)min((uint64_t)cnt, list_room);
+      cnt = min(cnt, kept > off ? kept - off : 0u);
     }
     const uint32_t incl = wave_inclusive_scan(cnt);
     if (live) {

@@ -69,6 +69,7 @@ struct vkrhip_ctx {
   // candidates
   uint64_t n_cand = 0;
   bool node_identity = true;
+  uint64_t node_limit = 0;  // 1 + the largest node index a candidate row names (explicit mapping)
   DevBuf<uint32_t> node;
   DevBuf<uint4> ident;
   DevBuf<float4> sphere;
@@ -710,10 +711,16 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
   if (n && (!ident || !matbits || !bounds)) return fail(c, VKRHIP_ERR_ARG, "null candidate array");
   if (!node && n > c->cfg.max_nodes)
     return fail(c, VKRHIP_ERR_ARG, "identity node mapping needs n <= max_nodes");
+  uint64_t node_limit = 0;
   if (node) {
-    for (uint64_t i = 0; i < n; ++i)
-      if (node[i] >= c->cfg.max_nodes)
-        return fail(c, VKRHIP_ERR_ARG, "node[%llu] = %u out of range", (unsigned long long)i, node[i]);
+    // a row must name a node of the bound hierarchy (any node slot before one is bound)
+    const uint64_t nodes = c->level_offsets.empty() ? c->cfg.max_nodes : c->n_nodes;
+    for (uint64_t i = 0; i < n; ++i) {
+      if (node[i] >= nodes)
+        return fail(c, VKRHIP_ERR_ARG, "node[%llu] = %u is not a node of the scene (%llu nodes)",
+                    (unsigned long long)i, node[i], (unsigned long long)nodes);
+      node_limit = std::max<uint64_t>(node_limit, (uint64_t)node[i] + 1u);
+    }
   }
   TRY(bind_device(c));
   uint64_t blend = 0;
@@ -732,6 +739,7 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
   }
   c->n_cand = n;
   c->node_identity = node == nullptr;
+  c->node_limit = node_limit;
   c->blend_rows = blend;
   c->published = false;  // the candidate words are rebuilt below; vkrhip_set_publication must follow
   if (n) {
@@ -1288,9 +1296,16 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
   if ((stages & VKRHIP_STAGE_ENCODE) &&
       (stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_PACK)) != (VKRHIP_STAGE_CULL | VKRHIP_STAGE_PACK))
     return fail(c, VKRHIP_ERR_STATE, "STAGE_ENCODE needs STAGE_CULL and STAGE_PACK in the same frame");
-  if ((stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_CANDIDATES)) && c->node_identity &&
-      c->n_cand > c->cfg.max_nodes)
-    return fail(c, VKRHIP_ERR_STATE, "identity node mapping with more candidates than nodes");
+  // every candidate row must name a node of the hierarchy as it is now (the
+  // hierarchy may have shrunk since the rows were bound)
+  if (stages & (VKRHIP_STAGE_CULL | VKRHIP_STAGE_CANDIDATES | VKRHIP_STAGE_PACK)) {
+    const uint64_t nodes = c->level_offsets.empty() ? c->cfg.max_nodes : c->n_nodes;
+    const uint64_t named = c->node_identity ? c->n_cand : c->node_limit;
+    if (named > nodes)
+      return fail(c, VKRHIP_ERR_STATE,
+                  "candidate rows name node %llu but the scene has %llu nodes: bind the rows again",
+                  (unsigned long long)(named - 1u), (unsigned long long)nodes);
+  }
   TRY(bind_device(c));
   const bool cull = (stages & VKRHIP_STAGE_CULL) != 0;
   const bool bounds_out = (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0;
@@ -1784,6 +1799,11 @@ int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, 
                           hipEvent_t packed = nullptr) {
   if (!c->frame_ran || !(c->last_stages & VKRHIP_STAGE_CULL))
     return fail(c, VKRHIP_ERR_STATE, "exchange needs a frame that ran the cull stage");
+  // with a publication the lists hold rank-local packed row indices, which
+  // collide between ranks when the lists are concatenated
+  if (c->published)
+    return fail(c, VKRHIP_ERR_STATE,
+                "the exchange merges source-row indices; it cannot run while a publication is set");
   ExchangePackArgs a{};
   a.states = c->states.p;
   a.visible = c->visible.p;
@@ -1803,6 +1823,41 @@ int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, 
   return VKRHIP_OK;
 }
 
+// The planning tables k_exchange_plan fills and k_exchange_apply reads.
+struct ExchangeTables {
+  uint64_t *desc;             // [views * 4][world] x {src word, dst word, count}
+  uint64_t *rank_view_start;  // [world][views]
+  uint64_t *prefix;           // [views * 4 + 1]
+  uint64_t *runs;             // [128]
+};
+
+// Plan + apply on `stream`; `done` (may be null) is recorded right behind the
+// last kernel by the launch itself. Allocates nothing.
+void launch_exchange_merge(const ExchangeTables &t, uint32_t views, const uint32_t *gathered_dev,
+                           uint32_t world, uint32_t vis_cap, uint32_t key_cap,
+                           uint32_t *merged_visible_dev, uint64_t *merged_keys_dev,
+                           uint64_t *result_dev, hipStream_t stream, hipEvent_t done) {
+  const uint32_t pairs = views * 4u;
+  ExchangePlanArgs a{};
+  a.gathered = gathered_dev;
+  a.desc = t.desc;
+  a.rank_view_start = t.rank_view_start;
+  a.prefix = t.prefix;
+  a.runs = t.runs;
+  a.result = result_dev;
+  a.world = world;
+  a.views = views;
+  a.vis_cap = vis_cap;
+  a.key_cap = key_cap;
+  hipLaunchKernelGGL(k_exchange_plan, dim3(1), dim3(SCAN_BLOCK), 0, stream, a);
+  // copy rows: enough blocks per descriptor to cover the largest possible range
+  const unsigned rows = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vis_cap, 4096), 1), 64);
+  const unsigned key_blocks = (unsigned)ceil_div((uint64_t)world * key_cap, 256);
+  hipExtLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
+                        nullptr, done, 0, gathered_dev, (const uint64_t *)t.desc, pairs * world, rows,
+                        merged_visible_dev, (const uint64_t *)t.runs, world, merged_keys_dev);
+}
+
 int enqueue_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t world,
                            uint32_t vis_cap, uint32_t key_cap, uint32_t *merged_visible_dev,
                            uint64_t *merged_keys_dev, uint64_t *result_dev, hipStream_t stream,
@@ -1814,26 +1869,9 @@ int enqueue_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t
   TRY(dev_alloc(c, c->exch_rank_view_start, (size_t)world * c->views));
   TRY(dev_alloc(c, c->exch_prefix, (size_t)pairs + 1));
   TRY(dev_alloc(c, c->exch_runs, 128));
-  ExchangePlanArgs a{};
-  a.gathered = gathered_dev;
-  a.desc = c->exch_desc.p;
-  a.rank_view_start = c->exch_rank_view_start.p;
-  a.prefix = c->exch_prefix.p;
-  a.runs = c->exch_runs.p;
-  a.result = result_dev;
-  a.world = world;
-  a.views = c->views;
-  a.vis_cap = vis_cap;
-  a.key_cap = key_cap;
-  hipLaunchKernelGGL(k_exchange_plan, dim3(1), dim3(SCAN_BLOCK), 0, stream, a);
-  // copy rows: enough blocks per descriptor to cover the largest possible range
-  const unsigned rows = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vis_cap, 4096), 1), 64);
-  const unsigned key_blocks = (unsigned)ceil_div((uint64_t)world * key_cap, 256);
-  // `done` (may be null) is recorded right behind the last kernel by the launch itself
-  hipExtLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
-                        nullptr, done, 0, gathered_dev, (const uint64_t *)c->exch_desc.p, pairs * world,
-                        rows, merged_visible_dev, (const uint64_t *)c->exch_runs.p, world,
-                        merged_keys_dev);
+  const ExchangeTables t{c->exch_desc.p, c->exch_rank_view_start.p, c->exch_prefix.p, c->exch_runs.p};
+  launch_exchange_merge(t, c->views, gathered_dev, world, vis_cap, key_cap, merged_visible_dev,
+                        merged_keys_dev, result_dev, stream, done);
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }

@@ -168,6 +168,9 @@ class HipShardSource:
     def exchange_scope(self):
         return self.torch.cuda.stream(self.exchange_stream)
 
+    def frame_serial(self) -> int:
+        return self.scene.frame_serial
+
     def pack(self, block, vis_cap: int, key_cap: int):
         self.scene.exchange_pack(block.data_ptr(), vis_cap, key_cap)
 
@@ -198,6 +201,19 @@ class HipShardSource:
         self.exchange_stream.synchronize()
 
 
+class ExchangeOverflow(RuntimeError):
+    """A rank's lists did not fit the exchange blocks and the frame can no longer
+    be repeated: the scene has been advanced since the run() that is being
+    finished, so a second pack would carry the newer frame's lists under the
+    older frame's name. Carries the capacities that would have fitted."""
+
+    def __init__(self, need_visible: int, need_keys: int):
+        super().__init__(f"exchange blocks overflowed (need {need_visible} visible indices, "
+                         f"{need_keys} keys per rank) after the scene advanced: call finish() before "
+                         "the next frame() until the blocks are sized")
+        self.need_visible, self.need_keys = need_visible, need_keys
+
+
 class _Buffers:
     __slots__ = ("send", "recv", "vis_merged", "key_merged", "result", "done")
 
@@ -217,6 +233,12 @@ class ShardExchange:
     Every rank must call run() and finish() in the same order: the capacities
     change only in finish(), from values every rank reads out of the same
     gathered headers, so the all-gather sizes always agree.
+
+    Overlapped use (frame k+1 enqueued before finish() of frame k) needs blocks
+    that already fit: a repeated exchange packs what the scene holds NOW, so
+    finish() refuses to repeat once the scene has advanced past the frame whose
+    run() it is finishing. Size the blocks with a finish() right after the first
+    run() (or pass capacities that cover the worst case).
     """
 
     def __init__(self, source, world: int, rank: int, views: int, group=None, device=None,
@@ -276,6 +298,7 @@ class ShardExchange:
         src = self.source
         b = self._sets[self._turn % len(self._sets)]
         self._turn += 1
+        self._run_serial = src.frame_serial() if hasattr(src, "frame_serial") else None
         if self.overlapped and b.done is not None:
             src.scene_wait(b.done)  # the exchange that used this set two frames ago
         with self._scene_scope():
@@ -312,6 +335,8 @@ class ShardExchange:
                 raise RuntimeError("exchange blocks were packed for different view counts")
             if not flags & (FLAG_VISIBLE_TRUNCATED | FLAG_KEYS_TRUNCATED):
                 break
+            if self._run_serial is not None and self.source.frame_serial() != self._run_serial:
+                raise ExchangeOverflow(int(res[1]), int(res[2]))
             vis_cap, key_cap = self.vis_cap, self.key_cap
             if int(res[1]) > vis_cap:
                 vis_cap = int(int(res[1]) * 1.25) + 1024
@@ -368,6 +393,7 @@ class RcclExchange:
 
     def run(self):
         self.scene.exchange_run()
+        self._run_serial = self.scene.frame_serial
         return self
 
     def finish(self):
@@ -379,6 +405,8 @@ class RcclExchange:
                 raise RuntimeError("exchange blocks were packed for different view counts")
             if not flags & (FLAG_VISIBLE_TRUNCATED | FLAG_KEYS_TRUNCATED):
                 break
+            if self.scene.frame_serial != self._run_serial:
+                raise ExchangeOverflow(int(res[1]), int(res[2]))
             vis_cap, key_cap = self.vis_cap, self.key_cap
             if int(res[1]) > vis_cap:
                 vis_cap = int(int(res[1]) * 1.25) + 1024

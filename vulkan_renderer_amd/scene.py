@@ -129,6 +129,7 @@ class HipScene:
         self.n_candidates = 0
         self.views = 0
         self.visible_capacity = visible_capacity or max_candidates
+        self.frame_serial = 0  # frames enqueued so far (the exchange checks it is repeating the right one)
 
     # ---- lifetime -------------------------------------------------------
     def close(self) -> None:
@@ -229,6 +230,7 @@ class HipScene:
     # ---- the frame ------------------------------------------------------
     def frame(self, stages: int = N.STAGE_ALL) -> None:
         self._ok(self.lib.vkrhip_frame(self.ctx, stages))
+        self.frame_serial += 1
 
     def frame_info(self) -> FrameResult:
         info = N.FrameInfo()
