@@ -421,6 +421,33 @@ int vkrhip_exchange_run(vkrhip_ctx *ctx);
 int vkrhip_exchange_finish(vkrhip_ctx *ctx, uint64_t *result_out,
                            const uint32_t **merged_visible_dev, const uint64_t **merged_keys_dev);
 
+/* ---- the exchange merge without an allocation -------------------------------
+ * No counterpart in the reference. For callers that cannot allocate device
+ * memory where they call: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. vkrhip_exchange_merge_static is
+ * vkrhip_exchange_merge without a context: same inputs, same outputs (merged
+ * visible lists, merged draw keys, result words as laid out above), but the
+ * planning tables its two kernels share live in a device array inside the
+ * library (VKRHIP_STATIC_SCRATCH_BYTES on every GPU the library is used on, held
+ * until the process ends) instead of buffers a context allocates. It calls no
+ * hipMalloc / hipFree, here or in anything it calls. Limits: world <=
+ * VKRHIP_STATIC_MAX_WORLD ranks and views <= VKRHIP_MAX_VIEWS; beyond them it
+ * returns VKRHIP_ERR_CAPACITY (message: vkrhip_last_error(NULL)).
+ *   device       HIP device the pointers live on; made current by the call
+ *   views        view count the blocks were packed for
+ *   hip_stream   stream the two kernels are enqueued on (NULL: the null stream)
+ * All calls on one GPU share that GPU's tables: calls that overlap on one GPU
+ * (different streams or threads) race; calls on one stream are ordered.
+ * vkrhip_static_init(device) looks the array's address up ahead of time (e.g.
+ * before a graph capture starts); otherwise the first call on a device does. */
+#define VKRHIP_STATIC_MAX_WORLD 8u
+#define VKRHIP_STATIC_SCRATCH_BYTES 56352u
+int vkrhip_static_init(int device);
+int vkrhip_exchange_merge_static(int device, uint32_t views, const uint32_t *gathered_dev,
+                                 uint32_t world, uint32_t vis_cap, uint32_t key_cap,
+                                 uint32_t *merged_visible_dev, uint64_t *merged_keys_dev,
+                                 uint64_t *result_dev, void *hip_stream);
+
 /* scene_entity_is_visible (vkr_scene_system.c:1935-1977) for every node of a
  * hierarchy stored parents-first (the order vkrhip_levelize produces): walking up
  * from a node, the first SceneVisibility with visible == 0 hides it, the first

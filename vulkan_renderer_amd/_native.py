@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_exchange_run", "vkrhip_exchange_finish", "vkrhip_candidate_epoch", "vkrhip_set_hzb", "vkrhip_build_hzb", "vkrhip_read_hzb", "vkrhip_read_transmission_candidates",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize", "vkrhip_effective_visibility",
+    "vkrhip_static_init", "vkrhip_exchange_merge_static",
 ]
 
 
@@ -197,6 +198,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_exchange_result_words.restype = u64
     L.vkrhip_exchange_pack.argtypes = [vp, vp, u32, u32]
     L.vkrhip_exchange_merge.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.vkrhip_static_init.argtypes = [C.c_int]
+    L.vkrhip_exchange_merge_static.argtypes = [C.c_int, u32, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vkrhip_frustum_from_matrix.argtypes = [vp, vp]
     L.vkrhip_frustum_from_matrix.restype = None
     L.vkrhip_frustum_from_view_projection.argtypes = [vp, vp, vp]

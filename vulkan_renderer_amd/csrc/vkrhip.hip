@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1999,6 +2000,93 @@ int vkrhip_exchange_finish(vkrhip_ctx *c, uint64_t *result_out, const uint32_t *
   HIP_TRY(c, hipStreamSynchronize(c->xstream));
   if (merged_visible_dev) *merged_visible_dev = x.merged_visible.p;
   if (merged_keys_dev) *merged_keys_dev = x.merged_keys.p;
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The exchange merge for callers that cannot allocate: the planning tables live
+// in a device array of the library instead of buffers a context allocates.
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t kStaticMaxWorld = VKRHIP_STATIC_MAX_WORLD;
+constexpr uint32_t kStaticMaxViews = VKRHIP_MAX_VIEWS;
+constexpr size_t kStaticDescWords = (size_t)kStaticMaxViews * 4u * kStaticMaxWorld * 3u;
+constexpr size_t kStaticStartWords = (size_t)kStaticMaxWorld * kStaticMaxViews;
+constexpr size_t kStaticPrefixWords = ((size_t)kStaticMaxViews * 4u + 1u + 3u) & ~(size_t)3u;
+constexpr size_t kStaticRunsWords = 128;
+constexpr size_t kStaticScratchWords =
+    kStaticDescWords + kStaticStartWords + kStaticPrefixWords + kStaticRunsWords;
+static_assert(kStaticScratchWords * sizeof(uint64_t) == VKRHIP_STATIC_SCRATCH_BYTES,
+              "the scratch size the header documents");
+
+// Every GPU the library runs on holds its own copy of this array, at its own
+// address, until the process ends. In host code the name is only a handle for
+// hipGetSymbolAddress: kernels and runtime calls get the per-device address
+// kept in g_scratch_ptr.
+static __device__ __align__(256) uint64_t scratch[kStaticScratchWords];
+
+constexpr int kStaticMaxDevices = 64;
+uint64_t *g_scratch_ptr[kStaticMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// Address of `scratch` on `device` (looked up once per device, with that device
+// current). Leaves `device` current.
+int static_scratch(int device, uint64_t **out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, VKRHIP_ERR_HIP, "no HIP device available");
+  if (device < 0 || device >= ndev || device >= kStaticMaxDevices)
+    return fail(nullptr, VKRHIP_ERR_ARG, "device %d out of range (0..%d)", device,
+                std::min(ndev, kStaticMaxDevices) - 1);
+  HIP_TRY(nullptr, hipSetDevice(device));
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    HIP_TRY(nullptr, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(nullptr, VKRHIP_ERR_HIP, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = static_cast<uint64_t *>(p);
+  }
+  *out = g_scratch_ptr[device];
+  return VKRHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vkrhip_static_init(int device) {
+  uint64_t *p = nullptr;
+  return static_scratch(device, &p);
+}
+
+int vkrhip_exchange_merge_static(int device, uint32_t views, const uint32_t *gathered_dev,
+                                 uint32_t world, uint32_t vis_cap, uint32_t key_cap,
+                                 uint32_t *merged_visible_dev, uint64_t *merged_keys_dev,
+                                 uint64_t *result_dev, void *hip_stream) {
+  if (!gathered_dev || !merged_visible_dev || !merged_keys_dev || !result_dev)
+    return fail(nullptr, VKRHIP_ERR_ARG, "null device pointer");
+  if (views == 0 || views > kStaticMaxViews)
+    return fail(nullptr, VKRHIP_ERR_CAPACITY, "views %u outside 1..%u", views, kStaticMaxViews);
+  if (world == 0 || world > kStaticMaxWorld)
+    return fail(nullptr, VKRHIP_ERR_CAPACITY,
+                "world size %u outside 1..%u: the planning tables of this entry point are a fixed "
+                "%u-byte device array (vkrhip_exchange_merge has no such limit)",
+                world, kStaticMaxWorld, (unsigned)VKRHIP_STATIC_SCRATCH_BYTES);
+  uint64_t *base = nullptr;
+  TRY(static_scratch(device, &base));
+  // every entry the apply kernel reads is written by the planning kernel of the
+  // same call first, so nothing of the previous call has to be cleared
+  ExchangeTables t{};
+  t.desc = base;
+  t.rank_view_start = t.desc + kStaticDescWords;
+  t.prefix = t.rank_view_start + kStaticStartWords;
+  t.runs = t.prefix + kStaticPrefixWords;
+  launch_exchange_merge(t, views, gathered_dev, world, vis_cap, key_cap, merged_visible_dev,
+                        merged_keys_dev, result_dev, (hipStream_t)hip_stream, nullptr);
+  HIP_TRY(nullptr, hipGetLastError());
   return VKRHIP_OK;
 }
 
