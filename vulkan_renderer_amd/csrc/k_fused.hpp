@@ -168,6 +168,42 @@ __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t ti
   h.fp = (h.fp | (dl << 1)) & ~(0x01010101u * F_DIRTY_LOCAL);
 }
 
+// The parents of a wave's 64 nodes. Siblings are contiguous in the BFS node
+// order and parents ascend with their children, so the 64 parents of a wave are
+// normally a handful of consecutive nodes: when they all lie in a window of 16
+// nodes [pmin, pmin + 16) the wave fetches that window with ONE load per lane
+// (lane L: column L & 3 of node pmin + (L >> 2); 1 KiB of consecutive bytes) and
+// the window's 16 flag bytes with another, a round ahead of their use, like the
+// matrices of the round. The columns reach the lanes that need them through
+// LDS, the flags by a wave shuffle. A wave whose parents are spread wider
+// (ok == false) falls back to one gather per sub-round when the round is
+// computed.
+struct FusedParent {
+  float4 pm;      // window column of this lane
+  uint32_t pf;    // flags of node pmin + (lane & 15)
+  uint32_t pmin;  // wave-uniform
+  bool ok;        // wave-uniform
+};
+
+// Needs a resolved head (h.p is NO_PARENT for roots and outside the level).
+__device__ __forceinline__ void fused_issue_parent(const FusedArgs &a, const FusedHead &h,
+                                                   FusedParent &par) {
+  // The window starts at the parent of the wave's first node that has one: in
+  // BFS order that is the smallest. Whether every other parent falls inside it
+  // is one compare and a vote (no reduction across the wave).
+  const unsigned long long have = __ballot(h.p != NO_PARENT);
+  const int first = have ? __ffsll((long long)have) - 1 : 0;
+  const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)h.p, first);
+  par.pmin = have ? p0 : 0u;
+  const unsigned long long inside = __ballot(h.p - par.pmin < 16u);
+  par.ok = (inside | ~have) == ~0ull;
+  // parents sit before the level, so the window is cut there (and stays inside the arrays)
+  const uint32_t last = a.t.begin ? (uint32_t)a.t.begin - 1u : 0u;
+  const uint32_t lane = threadIdx.x & 63u;
+  par.pm = a.t.world[(uint64_t)min(par.pmin + (lane >> 2), last) * 4u + (lane & 3u)];
+  par.pf = a.t.flags[min(par.pmin + (lane & 15u), last)];
+}
+
 // The local column of a node whose four lanes hold position, rotation and scale
 // (lanes 0, 1, 2 of the quad): scene_compute_local_matrix,
 // vkr_scene_system.c:555-561.
@@ -178,6 +214,53 @@ __device__ __forceinline__ float4 local_col_from_quad(float4 piece, uint32_t col
   return local_col_from_trs(pos, quat, scale, col);
 }
 
+// The kernel arguments arrive as 16-dword scalar loads, and the register
+// allocator treats every such group as ONE value: when it runs short of scalar
+// registers it parks the whole group in lanes of a vector register and brings
+// all sixteen dwords back for every use of one pointer. Passing each pointer
+// through an empty asm statement gives it a register pair (and a live range) of
+// its own, so the groups die right after the loads.
+template <typename T>
+__device__ __forceinline__ void own_sgprs(T *&p) {
+  asm volatile("" : "+s"(p));
+}
+__device__ __forceinline__ void own_sgprs(uint64_t &v) { asm volatile("" : "+s"(v)); }
+
+template <bool CULL>
+__device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
+  own_sgprs(a.t.parent);
+  own_sgprs(a.t.pos);
+  own_sgprs(a.t.quat);
+  own_sgprs(a.t.scale);
+  own_sgprs(a.t.local);
+  own_sgprs(a.t.world);
+  own_sgprs(a.t.flags);
+  own_sgprs(a.t.counters);
+  own_sgprs(a.t.begin);
+  own_sgprs(a.t.end);
+  if (CULL) {
+    own_sgprs(a.c.sphere);
+    own_sgprs(a.c.cflags);
+    own_sgprs(a.c.planes);
+    own_sgprs(a.c.planes_paired);
+    own_sgprs(a.c.tie_eps);
+    own_sgprs(a.c.required);
+    own_sgprs(a.c.view);
+    own_sgprs(a.c.tvis);
+    own_sgprs(a.c.tkey);
+    own_sgprs(a.c.world_bounds);
+    own_sgprs(a.c.stage);
+    own_sgprs(a.c.seg_counts);
+    own_sgprs(a.c.seg_first);
+    own_sgprs(a.c.counters);
+    own_sgprs(a.c.ties);
+    own_sgprs(a.c.n);
+    own_sgprs(a.c.stage_stride);
+    own_sgprs(a.c.seg_stride);
+    own_sgprs(a.c.index_base);
+  }
+}
+
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true>
 // Four waves per SIMD: a level of 1M nodes is exactly one resident set of blocks
 // (4 per CU), and the register budget of 128 lets the compiler keep the three
@@ -185,10 +268,14 @@ template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true>
 __global__ __launch_bounds__(FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[CULL ? FUSED_BLOCK * MAT_LDS_STRIDE : 1];  // wave w uses slots [64 w, 64 w + 64)
+  __shared__ float4 s_par[HAS_PARENT ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
   __shared__ uint32_t s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
   static_assert((F_DIRTY_LOCAL | F_DIRTY_WORLD | F_WORLD_UPDATED) < F_HAS_PARENT, "marker bit is free");
 
+  // (only where it pays: the root-level and tie-counting variants compile to more
+  // register traffic with separate values than with the groups)
+  if (HAS_PARENT && !TIES) split_argument_groups<CULL>(a);
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
   // Small levels are cut into more blocks of fewer rounds: a lone block per CU
@@ -220,10 +307,12 @@ k_propagate_classify(FusedArgs a) {
   // round r+1 and the head of round r+2 are in flight.
   FusedHead head_next, head_after;
   FusedBody body_next;
+  FusedParent par_next;
   if (active(0)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, 0u, head_next);
   if (active(1)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
   if (active(0)) {
     fused_resolve_head(a, tile_base, lo, hi, 0u, head_next);
+    if (HAS_PARENT) fused_issue_parent(a, head_next, par_next);
     fused_issue_body(a, tile_base, lo, hi, 0u, head_next, body_next);
   }
   uint32_t updated_here = 0;
@@ -235,9 +324,12 @@ k_propagate_classify(FusedArgs a) {
     const uint64_t base = tile_base + rbase;
     FusedHead hd = head_next;
     FusedBody cur = body_next;
+    FusedParent par = par_next;
     head_next = head_after;
     if (active(round + 1)) {
       fused_resolve_head(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
+      // ahead of the matrices: loads return in issue order and the window is needed first
+      if (HAS_PARENT) fused_issue_parent(a, head_next, par_next);
       fused_issue_body(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
     if (active(round + 2))
@@ -245,22 +337,13 @@ k_propagate_classify(FusedArgs a) {
     if (!active(round)) continue;
 
     // ---- transform phase -------------------------------------------------------
-    // Parents were finished by the previous level's launch. The four lanes of a
-    // node fetch one column each of the parent's world matrix; the parent index
-    // sits in the lane that loaded it for the cull mapping. Siblings share their
-    // parent, so the requests of a sub-round merge into a few cache lines.
-    float4 pc[HAS_PARENT ? 4 : 1];
-    uint32_t pfp = 0u;  // per sub-round byte: the parent's flags | F_HAS_PARENT, 0 for a root
+    // Parents were finished by the previous level's launch. The wave's parent
+    // window arrived with the round's matrices; it is spread over the wave's
+    // stretch of LDS so that the four lanes of a node can pick one column each of
+    // their parent's world matrix.
     if (HAS_PARENT) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t par = (uint32_t)__shfl((int)hd.p, r * 16 + (int)((t & 63u) >> 2), 64);
-        const uint32_t pm = par != NO_PARENT ? 0xffffffffu : 0u;
-        const uint64_t pidx = par & pm;  // roots read node 0 and drop the result
-        pc[r] = a.t.world[pidx * 4u + col];
-        const uint32_t pflag = a.t.flags[pidx];
-        pfp |= (((pflag & 0x7fu) | F_HAS_PARENT) & pm & 0xffu) << (8 * r);
-      }
+      if (par.ok) s_par[t] = par.pm;
+      __builtin_amdgcn_wave_barrier();  // a wave's LDS accesses stay in order
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -273,7 +356,24 @@ k_propagate_classify(FusedArgs a) {
         lcol = local_col_from_quad(lcol, col);
         if (valid) a.t.local[node * 4u + col] = lcol;
       }
-      const uint32_t pf = HAS_PARENT ? (pfp >> (8 * r)) & 0xffu : 0u;
+      float4 pcr = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t pf = 0u;  // the parent's flags | F_HAS_PARENT, 0 for a root
+      if (HAS_PARENT) {
+        // the parent index sits in the lane that loaded it for the cull mapping
+        const uint32_t par_node = (uint32_t)__shfl((int)hd.p, r * 16 + (int)((t & 63u) >> 2), 64);
+        const uint32_t pm = par_node != NO_PARENT ? 0xffffffffu : 0u;
+        uint32_t pflag;
+        if (par.ok) {  // wave-uniform
+          const uint32_t k = (par_node - par.pmin) & 15u;
+          pcr = s_par[(t & ~63u) + k * 4u + col];
+          pflag = (uint32_t)__shfl((int)par.pf, (int)k, 64);
+        } else {
+          const uint64_t pidx = par_node & pm;  // roots read node 0 and drop the result
+          pcr = a.t.world[pidx * 4u + col];
+          pflag = a.t.flags[pidx];
+        }
+        pf = ((pflag & 0x7fu) | F_HAS_PARENT) & pm & 0xffu;
+      }
       // deferred dirty propagation, vkr_scene_system.c:1310-1316
       if (HAS_PARENT && valid && (pf & F_WORLD_UPDATED) && !(fr & F_DIRTY_WORLD)) {
         lcol = a.t.local[node * 4u + col];  // the parent moved: this node moves too
@@ -287,10 +387,10 @@ k_propagate_classify(FusedArgs a) {
       }
       if (HAS_PARENT) {
         // all four lanes of the node take part in the column exchange
-        const float4 a0 = quad_bcast4<0>(pc[r]);
-        const float4 a1 = quad_bcast4<1>(pc[r]);
-        const float4 a2 = quad_bcast4<2>(pc[r]);
-        const float4 a3 = quad_bcast4<3>(pc[r]);
+        const float4 a0 = quad_bcast4<0>(pcr);
+        const float4 a1 = quad_bcast4<1>(pcr);
+        const float4 a2 = quad_bcast4<2>(pcr);
+        const float4 a3 = quad_bcast4<3>(pcr);
         if (did_update && (pf & F_HAS_PARENT)) wcol = mat4_mul_col(a0, a1, a2, a3, lcol);
       }
       if (did_update) a.t.world[node * 4u + col] = wcol;
