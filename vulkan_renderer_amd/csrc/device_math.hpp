@@ -68,10 +68,33 @@ __host__ __device__ __forceinline__ float4 mat4_mul_col(const float4 a0, const f
   return t;
 }
 
+// mat4_mul with the left matrix taken one column at a time (k = 0..3): after step
+// k every result element holds the first k + 1 terms of the reference's chain
+// (one rounded multiply, then fused multiply-adds in k order), so the result is
+// the same bit for bit, and only one column of the left matrix has to be in
+// registers at a time.
+__host__ __device__ __forceinline__ void mat4_mul_step(int k, const float4 ak, const float4 b,
+                                                       float4 &acc) {
+  const float s = k == 0 ? b.x : (k == 1 ? b.y : (k == 2 ? b.z : b.w));
+  if (k == 0) {
+    acc.x = ak.x * s;
+    acc.y = ak.y * s;
+    acc.z = ak.z * s;
+    acc.w = ak.w * s;
+  } else {
+    acc.x = fma_rn(ak.x, s, acc.x);
+    acc.y = fma_rn(ak.y, s, acc.y);
+    acc.z = fma_rn(ak.z, s, acc.z);
+    acc.w = fma_rn(ak.w, s, acc.w);
+  }
+}
+
 __host__ __device__ __forceinline__ Mat4 mat4_mul(const Mat4 &a, const Mat4 &b) {
-  Mat4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.c[i] = mat4_mul_col(a.c[0], a.c[1], a.c[2], a.c[3], b.c[i]);
+  Mat4 r;  // (no loop: a column index that is not a constant would put the matrix in memory)
+  r.c[0] = mat4_mul_col(a.c[0], a.c[1], a.c[2], a.c[3], b.c[0]);
+  r.c[1] = mat4_mul_col(a.c[0], a.c[1], a.c[2], a.c[3], b.c[1]);
+  r.c[2] = mat4_mul_col(a.c[0], a.c[1], a.c[2], a.c[3], b.c[2]);
+  r.c[3] = mat4_mul_col(a.c[0], a.c[1], a.c[2], a.c[3], b.c[3]);
   return r;
 }
 

@@ -440,27 +440,41 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
   if (t == 0) a.seg_first[seg] = (uint32_t)first;
   __syncthreads();
 
+  // View by view, the four rounds of the thread side by side: their mask reads
+  // are independent, so a view costs one LDS round trip, not four.
+  unsigned long long below[CULL_ROUNDS];  // lower lanes of the slot holding this lane's bucket
+  const uint16_t *start[CULL_ROUNDS];
+  uint32_t rel[CULL_ROUNDS];
 #pragma unroll
   for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
     const uint32_t bucket = (packed >> (8u * round)) & 0xfu;
-    const bool tv = ((packed >> (8u * round)) & 0x10u) != 0u;
-    const uint32_t rel = round * CULL_BLOCK + t - tile_to_first;  // candidate index - first
     const uint32_t slot = round * (CULL_BLOCK / 64u) + wave;
-    const uint16_t *start = s.cnt + slot * s.rows;
-    // lower lanes holding this lane's bucket
-    const unsigned long long below_same_bucket = bucket < 4u ? s.inb[slot * 4u + bucket] & lt_mask : 0ull;
-    for (uint32_t v = 0; v < a.views; ++v) {
-      const unsigned long long mp = s.mask[slot * a.views + v];  // the same for the whole wave
-      if (mp == 0ull) continue;
-      if ((mp >> lane) & 1ull) {
-        const uint32_t pos = start[v * 4u + bucket] + (uint32_t)__popcll(mp & below_same_bucket);
-        a.stage[(uint64_t)v * a.stage_stride + first + pos] = (uint32_t)first + rel;
+    rel[round] = round * CULL_BLOCK + t - tile_to_first;  // candidate index - first
+    below[round] = bucket < 4u ? s.inb[slot * 4u + bucket] & lt_mask : 0ull;
+    start[round] = s.cnt + slot * s.rows + (bucket & 3u);
+  }
+  for (uint32_t v = 0; v < a.views; ++v) {
+    unsigned long long mp[CULL_ROUNDS];
+#pragma unroll
+    for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round)
+      mp[round] = s.mask[(round * (CULL_BLOCK / 64u) + wave) * a.views + v];  // the same for the whole wave
+    uint32_t *list = a.stage + (uint64_t)v * a.stage_stride + first;
+#pragma unroll
+    for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
+      if (mp[round] == 0ull) continue;  // wave-uniform
+      if ((mp[round] >> lane) & 1ull) {
+        const uint32_t pos = start[round][v * 4u] + (uint32_t)__popcll(mp[round] & below[round]);
+        list[pos] = (uint32_t)first + rel[round];
       }
     }
-    if (tv) {
+  }
+#pragma unroll
+  for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
+    if ((packed >> (8u * round)) & 0x10u) {  // a visible blend row
+      const uint32_t slot = round * (CULL_BLOCK / 64u) + wave;
       const unsigned long long mt = s.tmask[slot];
-      const uint32_t pos = start[a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
-      a.stage[(uint64_t)a.views * a.stage_stride + first + pos] = (uint32_t)first + rel;
+      const uint32_t pos = s.cnt[slot * s.rows + a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
+      a.stage[(uint64_t)a.views * a.stage_stride + first + pos] = (uint32_t)first + rel[round];
     }
   }
   if (t == 0) {

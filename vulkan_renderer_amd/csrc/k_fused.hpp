@@ -14,20 +14,19 @@
 // round r+2 are requested before round r is consumed, so a block always has
 // more than a round's worth of HBM requests in flight while it computes.
 //
-// Inside a round every wave works on its own 64 consecutive nodes and never
-// waits for another wave:
-//   transform phase  4 lanes per node, lane j owns column j, four sub-rounds of
-//                    16 nodes: every wave load/store covers 1 KiB of consecutive
-//                    bytes. Below the root level the four lanes of a node fetch
-//                    one column each of the parent's world matrix (siblings are
-//                    contiguous in the BFS node order, so the 16 nodes of a
-//                    sub-round share a couple of parents and the requests merge)
-//                    and trade columns with quad DPP moves; the parent index
-//                    comes from the lane that loaded it by a wave shuffle;
-//   hand-over        the world columns go to the wave's stretch of LDS with an
-//                    80-byte node stride (conflict-free 16-byte reads);
-//   cull phase       one thread per node reads its four columns back and runs
-//                    classify_candidate().
+// Two lane layouts meet in every round, and a wave only ever works on its own 64
+// consecutive nodes, so it never waits for another wave:
+//   memory layout   "column lanes": lane L of a wave moves column L & 3 of node
+//                   16 r + (L >> 2) of the wave in step r = 0..3, so every wave
+//                   load / store of matrices covers 1 KiB of consecutive bytes;
+//   compute layout  thread t owns node t of the round: flags, the 4x4 product
+//                   with the parent's world matrix and classify_candidate() run
+//                   once per node, with the whole matrix in the thread's
+//                   registers.
+// The wave's stretch of LDS (80-byte node stride: conflict-free 16-byte
+// accesses in both layouts) transposes between the two: columns in after the
+// loads, columns out before the stores. Below the root level the parents of the
+// wave's nodes arrive as one prefetched window (FusedParent).
 // The only block-wide barriers are the one after the LDS tables are cleared and
 // those of the end-of-segment packing.
 #pragma once
@@ -38,50 +37,86 @@ namespace vkr {
 
 constexpr int FUSED_BLOCK = 256;
 constexpr int FUSED_ROUNDS = CULL_TILE / FUSED_BLOCK;  // 4
-constexpr uint32_t F_HAS_PARENT = 0x80u;  // marker in the prefetched parent flag byte (not a scene flag)
+constexpr uint32_t F_HAS_PARENT = 0x80u;  // marker in the parent flag byte (not a scene flag)
+
+// One block of the merged top levels (TOP = true): its tile, and where its
+// ancestors sit in the flattened ancestor tables. The first levels of a
+// hierarchy are small; instead of a launch per level, whose duration is one
+// block's chain of dependent loads, ONE launch covers them, and every block
+// first recomputes the world matrices of its nodes' ancestors itself - from the
+// same inputs with the same operations in the same order as the blocks that own
+// those nodes, hence bit for bit the same values - so no block waits for
+// another. Ancestors are listed root side first; entry e has the node index
+// anc_node[e] and anc_info[e] = the slot of its parent among the block's entries
+// (0xffff: a root) | its step in the chain << 16. Everything here is a function
+// of the hierarchy alone and is built when the hierarchy is bound.
+constexpr uint32_t TOP_MAX_ANCESTORS = 256;  // one thread per ancestor
+struct TopDesc {
+  uint32_t tile_base;  // first node of the block's 1024-node tile
+  uint32_t lo_hi;      // the block's part of the tile: lo | hi << 16
+  uint32_t anc_off;    // first entry of the block in anc_node / anc_info
+  uint32_t anc_count;
+  uint32_t par_first;  // the parents of the block's nodes are the entries
+  uint32_t par_slot;   //   [par_slot, ...) = nodes [par_first, ...)
+  uint32_t steps;      // chain steps (levels that hold ancestors)
+  uint32_t reserved;
+};
 
 struct FusedArgs {
   TransformArgs t;
   CullArgs c;         // c.n = candidates; candidate i <-> node i
   uint32_t rounds;    // rounds of a tile one block walks: 4, 2 or 1 (more, shorter blocks)
   uint32_t seg_base;  // cull segment of block 0 of this launch (segments follow launch order)
+  // merged top levels only
+  const TopDesc *top;
+  const uint32_t *top_anc_node;
+  const uint32_t *top_anc_info;
+  uint32_t top_lds_offset;  // bytes of dynamic LDS ahead of the ancestor table (the cull tables)
+  uint32_t top_anc_cap;     // entries the ancestor table is sized for
 };
 
-// Value of lane (quad base + K) for every lane of the quad (quad_perm DPP move).
-template <int K>
-__device__ __forceinline__ float quad_bcast(float v) {
-  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true));
-}
-template <int K>
-__device__ __forceinline__ float4 quad_bcast4(float4 v) {
-  return make_float4(quad_bcast<K>(v.x), quad_bcast<K>(v.y), quad_bcast<K>(v.z), quad_bcast<K>(v.w));
-}
-
-// Node a lane works on in sub-round r of a round, relative to the round's first
-// node: the wave's 64 nodes in four groups of 16, four lanes per node.
+// Node a lane moves a column of in step r of a round, relative to the round's
+// first node (memory layout): the wave's 64 nodes in four groups of 16.
 __device__ __forceinline__ uint32_t sub_slot(int r) {
   return (threadIdx.x & ~63u) + (uint32_t)r * 16u + ((threadIdx.x & 63u) >> 2);
 }
 
+// Sixteen bytes that only pass through registers on their way from global memory
+// to LDS. As the native vector type the copies are one load and one store; as
+// float4 (a struct) the compiler chains block copies through a stack slot.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Element `index` of an array whose base is the same for the whole wave, addressed
+// as that base (a scalar register pair) plus a 32-bit byte offset per lane: no
+// 64-bit address arithmetic and no 64-bit address registers per lane. The caller
+// guarantees that index * sizeof(T) fits 32 bits.
+template <typename T>
+__device__ __forceinline__ const T *at32(const T *uniform_base, uint32_t index) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(uniform_base) +
+                                     index * (uint32_t)sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ T *at32(T *uniform_base, uint32_t index) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
+}
+
 // What one thread loads for one round, in two dependent steps: the head (flags,
-// parent index, cull inputs) depends on nothing; the matrix columns are picked
-// by the flags of the head. Both steps are unconditional loads from clamped
-// indices whose results are masked with integer arithmetic afterwards (a
-// select on a loaded value would be turned back into a branch around the load,
-// and every such branch waits for its own load), so all loads of a step are
-// issued back to back and the rounds can be software-pipelined. Positions are
-// 32-bit offsets into the block's 1024-node tile; [lo, hi) is the part of the
-// tile that belongs to the level.
+// parent index, cull inputs of its own node) depends on nothing; the matrix
+// columns are picked by the flags of the head. Both steps are unconditional
+// loads from clamped indices whose results are masked with integer arithmetic
+// afterwards (a select on a loaded value would be turned back into a branch
+// around the load, and every such branch waits for its own load), so all loads
+// of a step are issued back to back and the rounds can be software-pipelined.
+// Positions are 32-bit offsets into the block's 1024-node tile; [lo, hi) is the
+// part of the tile that belongs to the level.
 struct FusedHead {
-  uint32_t raw[4];  // node flag bytes as loaded (sub-round mapping)
-  uint32_t fp;      // after fused_resolve_head: the four pass-1 flag bytes packed (byte r =
-                    // sub-round r), 0 outside the level
-  uint32_t rebuild; // after fused_issue_body: bit r = sub-round r rebuilds its local matrix from TRS
-  uint32_t p;       // parent of node (round base + thread)
-  float4 ls;        // local sphere of candidate (round base + thread)
-  uint32_t cf;
-  __device__ __forceinline__ uint32_t f(int r) const { return (fp >> (8 * r)) & 0xffu; }
+  uint32_t f;    // flag byte of node (round base + thread); after fused_resolve_head the
+                 // pass-1 flags, 0 outside the level
+  uint32_t p;    // parent of that node
+  f32x4 ls;      // local sphere and candidate word of candidate (round base + thread): two
+  uint32_t cf;   // rounds ahead like the flags (with the matrices, a round later, the frame
+                 // of a 16M-node hierarchy takes 3 % longer)
+  bool rebuild;  // after fused_issue_body: the node's local matrix is rebuilt from its TRS
 };
 
 __device__ __forceinline__ uint32_t clamp_rel(uint32_t rel, uint32_t lo, uint32_t hi) {
@@ -95,20 +130,19 @@ template <bool HAS_PARENT, bool CULL>
 __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h) {
-  const uint32_t t = threadIdx.x;
-  const uint64_t i = tile_base + clamp_rel(rbase + t, lo, hi);
+  const uint32_t rel = clamp_rel(rbase + threadIdx.x, lo, hi);  // < 1024: every offset fits 32 bits
+  h.f = *at32(a.t.flags_in + tile_base, rel);
   h.p = NO_PARENT;
-  if (HAS_PARENT) h.p = a.t.parent[i];
-  h.ls = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (HAS_PARENT) h.p = *at32(a.t.parent + tile_base, rel);
+  h.ls = f32x4{0.f, 0.f, 0.f, 0.f};
   h.cf = 0u;
   if (CULL) {
-    const uint64_t ci = min(i, a.c.n - 1u);
-    h.ls = a.c.sphere[ci];
-    h.cf = a.c.cflags[ci];
+    // (candidate i <-> node i; the tile's first node is a candidate, or the block has none to classify)
+    const uint64_t cbase = min(tile_base, a.c.n - 1u);
+    const uint32_t crel = (uint32_t)min((uint64_t)rel, a.c.n - 1u - cbase);
+    h.ls = *at32(reinterpret_cast<const f32x4 *>(a.c.sphere) + cbase, crel);
+    h.cf = *at32(a.c.cflags + cbase, crel);
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    h.raw[r] = a.t.flags[tile_base + clamp_rel(rbase + sub_slot(r), lo, hi)];
 }
 
 // Waits for the head's loads. Applies the bulk dirty bits and pass 1's clearing
@@ -116,56 +150,62 @@ __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t ti
 __device__ __forceinline__ void fused_resolve_head(const FusedArgs &a, uint64_t tile_base,
                                                    uint32_t lo, uint32_t hi, uint32_t rbase,
                                                    FusedHead &h) {
-  const uint32_t t = threadIdx.x;
-  const uint32_t rel = rbase + t;
+  const uint32_t rel = rbase + threadIdx.x;
   uint32_t m = in_range_mask(rel, lo, hi);
+  h.f = ((h.f | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & m & 0xffu;
   h.p |= ~m;  // NO_PARENT outside the level
-  if (tile_base + rel >= a.c.n) m = 0u;
-  h.cf = (h.cf & m) | (0xf0u & ~m);  // invalid bucket: fails every gate
-  h.fp = 0u;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint32_t mr = in_range_mask(rbase + sub_slot(r), lo, hi);
-    h.fp |= ((((h.raw[r] | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & mr) & 0xffu) << (8 * r);
-  }
 }
 
 struct FusedBody {
-  // per sub-round: the local column when the node is dirty, the stored world
-  // column when it is clean, and one piece of the node's TRS when the local
-  // matrix has to be rebuilt (lane 0 position, 1 rotation, 2 scale)
-  float4 m[4];
+  // memory layout, per step: the local column when the node is dirty, the stored
+  // world column when it is clean, and one piece of the node's TRS when the local
+  // matrix has to be rebuilt (column lane 0 position, 1 rotation, 2 scale)
+  f32x4 m0, m1, m2, m3;
+  template <int R>
+  __device__ __forceinline__ f32x4 &at() {
+    if constexpr (R == 0) return m0;
+    if constexpr (R == 1) return m1;
+    if constexpr (R == 2) return m2;
+    return m3;
+  }
 };
 
-// Needs a resolved head. The node's own flags pick what to fetch: dirty -> the
-// local column; clean -> the stored world column (the cull phase needs it
+// Needs a resolved head. A node's own flags pick what to fetch for it: dirty ->
+// the local matrix; clean -> the stored world matrix (the cull phase needs it
 // unless the parent turns out to have moved, which is handled when the round is
-// computed); TRS changed (pass 1, vkr_scene_system.c:598-602) -> the four lanes
-// of the node fetch position, rotation and scale, one 16-byte piece each, and
-// the local matrix is rebuilt from them when the round is computed. Either way
-// it is one unconditional load per sub-round.
-__device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t tile_base,
-                                                 uint32_t lo, uint32_t hi, uint32_t rbase,
-                                                 FusedHead &h, FusedBody &b) {
+// computed); TRS changed (pass 1, vkr_scene_system.c:598-602) -> position,
+// rotation and scale, from which the local matrix is rebuilt when the round is
+// computed. The column lanes learn the flags of the node they fetch for from
+// the lane that owns it (a wave shuffle). One unconditional load per step.
+template <int R>
+__device__ __forceinline__ void fused_issue_column(const FusedArgs &a, uint64_t tile_base,
+                                                   uint32_t lo, uint32_t hi, uint32_t rbase,
+                                                   const FusedHead &h, FusedBody &b) {
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
   const bool have_trs = a.t.pos != nullptr;
   const float4 *piece = col == 1u ? a.t.quat : (col == 2u ? a.t.scale : a.t.pos);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const uint64_t node = tile_base + clamp_rel(rbase + sub_slot(r), lo, hi);
-    const uint32_t f = h.f(r);
-    const bool hl = (f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
-    const bool rebuilt = have_trs && (f & F_DIRTY_LOCAL) != 0;
-    const float4 *src = rebuilt ? piece + node : (hl ? a.t.local : a.t.world) + node * 4u + col;
-    b.m[r] = *src;
-  }
-  // DIRTY_LOCAL becomes DIRTY_WORLD (all four bytes at once); from here on a set
-  // DIRTY_WORLD bit also says that b.m holds the local column or, where
-  // h.rebuild says so, the piece it is rebuilt from
-  const uint32_t dl = h.fp & (0x01010101u * F_DIRTY_LOCAL);
-  h.rebuild = have_trs ? ((dl | (dl >> 7) | (dl >> 14) | (dl >> 21)) & 0xfu) : 0u;
-  h.fp = (h.fp | (dl << 1)) & ~(0x01010101u * F_DIRTY_LOCAL);
+  const uint64_t node = tile_base + clamp_rel(rbase + sub_slot(R), lo, hi);
+  const uint32_t f = (uint32_t)__shfl((int)h.f, R * 16 + (int)((t & 63u) >> 2), 64);
+  const bool hl = (f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
+  const bool rebuilt = have_trs && (f & F_DIRTY_LOCAL) != 0;
+  const float4 *src = rebuilt ? piece + node : (hl ? a.t.local : a.t.world) + node * 4u + col;
+  b.at<R>() = *reinterpret_cast<const f32x4 *>(src);
+}
+
+template <bool CULL>
+__device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t tile_base,
+                                                 uint32_t lo, uint32_t hi, uint32_t rbase,
+                                                 FusedHead &h, FusedBody &b) {
+  fused_issue_column<0>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<1>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<2>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<3>(a, tile_base, lo, hi, rbase, h, b);
+  const bool have_trs = a.t.pos != nullptr;
+  // DIRTY_LOCAL becomes DIRTY_WORLD; from here on a set DIRTY_WORLD bit also says
+  // that the fetched matrix is the local one or, where h.rebuild says so, the TRS
+  h.rebuild = have_trs && (h.f & F_DIRTY_LOCAL) != 0;
+  h.f = (h.f | ((h.f & F_DIRTY_LOCAL) << 1)) & ~(uint32_t)F_DIRTY_LOCAL;
 }
 
 // The parents of a wave's 64 nodes. Siblings are contiguous in the BFS node
@@ -174,10 +214,9 @@ __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t ti
 // nodes [pmin, pmin + 16) the wave fetches that window with ONE load per lane
 // (lane L: column L & 3 of node pmin + (L >> 2); 1 KiB of consecutive bytes) and
 // the window's 16 flag bytes with another, a round ahead of their use, like the
-// matrices of the round. The columns reach the lanes that need them through
+// matrices of the round. The columns reach the threads that need them through
 // LDS, the flags by a wave shuffle. A wave whose parents are spread wider
-// (ok == false) falls back to one gather per sub-round when the round is
-// computed.
+// (ok == false) falls back to a gather per thread when the round is computed.
 struct FusedParent {
   float4 pm;      // window column of this lane
   uint32_t pf;    // flags of node pmin + (lane & 15)
@@ -201,17 +240,37 @@ __device__ __forceinline__ void fused_issue_parent(const FusedArgs &a, const Fus
   const uint32_t last = a.t.begin ? (uint32_t)a.t.begin - 1u : 0u;
   const uint32_t lane = threadIdx.x & 63u;
   par.pm = a.t.world[(uint64_t)min(par.pmin + (lane >> 2), last) * 4u + (lane & 3u)];
-  par.pf = a.t.flags[min(par.pmin + (lane & 15u), last)];
+  par.pf = a.t.flags_out[min(par.pmin + (lane & 15u), last)];  // as the parents' launch left them
 }
 
-// The local column of a node whose four lanes hold position, rotation and scale
-// (lanes 0, 1, 2 of the quad): scene_compute_local_matrix,
-// vkr_scene_system.c:555-561.
-__device__ __forceinline__ float4 local_col_from_quad(float4 piece, uint32_t col) {
-  const float4 pos = quad_bcast4<0>(piece);
-  const float4 quat = quad_bcast4<1>(piece);
-  const float4 scale = quad_bcast4<2>(piece);
-  return local_col_from_trs(pos, quat, scale, col);
+// Moves one matrix per thread (compute layout) out to global memory in the
+// memory layout, through the wave's stretch of LDS: every wave store covers
+// 1 KiB of consecutive bytes. `want` marks the wave's threads whose matrix is
+// to be stored (wave-uniform value, bit = lane).
+__device__ __forceinline__ void store_matrices(float4 *s_mat, float4 *dst, uint64_t round_base,
+                                               float4 c0, float4 c1, float4 c2, float4 c3,
+                                               unsigned long long want) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t col = t & 3u;
+  float4 *own = s_mat + t * MAT_LDS_STRIDE;
+  own[0] = c0;
+  own[1] = c1;
+  own[2] = c2;
+  own[3] = c3;
+  __builtin_amdgcn_wave_barrier();  // a wave's LDS accesses stay in order
+  // step r is step 0 plus a constant: one address register per array, the rest
+  // goes into the instructions' offset fields
+  const uint32_t slot0 = sub_slot(0);
+  const float4 *in0 = s_mat + slot0 * MAT_LDS_STRIDE + col;
+  float4 *out0 = at32(dst + round_base * 4u, slot0 * 4u + col);
+  const uint32_t lane_bit = (t & 63u) >> 2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 v = in0[r * 16 * MAT_LDS_STRIDE];
+    const uint32_t chunk = (uint32_t)(want >> (16 * r)) & 0xffffu;  // scalar
+    if ((chunk >> lane_bit) & 1u) out0[r * 16 * 4] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 // The kernel arguments arrive as 16-dword scalar loads, and the register
@@ -220,9 +279,15 @@ __device__ __forceinline__ float4 local_col_from_quad(float4 piece, uint32_t col
 // all sixteen dwords back for every use of one pointer. Passing each pointer
 // through an empty asm statement gives it a register pair (and a live range) of
 // its own, so the groups die right after the loads.
+// (The statement hides where the value came from, and with it the fact that it is
+// a pointer to global memory; the address space is stated again afterwards, or
+// every access through it would become a flat instruction, which counts on both
+// memory counters and defeats the partial waits of the software pipeline.)
 template <typename T>
 __device__ __forceinline__ void own_sgprs(T *&p) {
-  asm volatile("" : "+s"(p));
+  uint64_t v = (uint64_t)p;
+  asm volatile("" : "+s"(v));
+  p = (T *)(T __attribute__((address_space(1))) *)v;
 }
 __device__ __forceinline__ void own_sgprs(uint64_t &v) { asm volatile("" : "+s"(v)); }
 
@@ -234,7 +299,8 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
   own_sgprs(a.t.scale);
   own_sgprs(a.t.local);
   own_sgprs(a.t.world);
-  own_sgprs(a.t.flags);
+  own_sgprs(a.t.flags_in);
+  own_sgprs(a.t.flags_out);
   own_sgprs(a.t.counters);
   own_sgprs(a.t.begin);
   own_sgprs(a.t.end);
@@ -261,14 +327,15 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
   }
 }
 
-template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true>
+template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false>
 // Four waves per SIMD: a level of 1M nodes is exactly one resident set of blocks
 // (4 per CU), and the register budget of 128 lets the compiler keep the three
 // pipeline stages apart.
 __global__ __launch_bounds__(FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 k_propagate_classify(FusedArgs a) {
-  __shared__ float4 s_mat[CULL ? FUSED_BLOCK * MAT_LDS_STRIDE : 1];  // wave w uses slots [64 w, 64 w + 64)
-  __shared__ float4 s_par[HAS_PARENT ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
+  __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
+  __shared__ float4 s_par[HAS_PARENT && !TOP ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
+  static_assert(!TOP || HAS_PARENT, "the merged top levels hold nodes with parents");
   __shared__ uint32_t s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
   static_assert((F_DIRTY_LOCAL | F_DIRTY_WORLD | F_WORLD_UPDATED) < F_HAS_PARENT, "marker bit is free");
@@ -278,17 +345,26 @@ k_propagate_classify(FusedArgs a) {
   if (HAS_PARENT && !TIES) split_argument_groups<CULL>(a);
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
-  // Small levels are cut into more blocks of fewer rounds: a lone block per CU
-  // cannot hide its own load latency.
-  const uint32_t per_tile = (uint32_t)FUSED_ROUNDS / a.rounds;
-  const uint64_t tile = a.t.begin / CULL_TILE + blockIdx.x / per_tile;
-  const uint64_t tile_base = tile * CULL_TILE;
-  const uint32_t first_round = (blockIdx.x % per_tile) * a.rounds;
-  // the block's part of the level, as offsets into the tile
-  uint32_t lo = a.t.begin > tile_base ? (uint32_t)(a.t.begin - tile_base) : 0u;
-  uint32_t hi = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tile_base);
-  lo = max(lo, first_round * FUSED_BLOCK);
-  hi = min(hi, (first_round + a.rounds) * FUSED_BLOCK);
+  uint64_t tile_base;
+  uint32_t lo, hi;  // the block's part of the level, as offsets into the tile
+  TopDesc top{};
+  if (TOP) {
+    top = a.top[blockIdx.x];  // block-uniform: scalar loads
+    tile_base = top.tile_base;
+    lo = top.lo_hi & 0xffffu;
+    hi = top.lo_hi >> 16;
+  } else {
+    // Small levels are cut into more blocks of fewer rounds: a lone block per CU
+    // cannot hide its own load latency.
+    const uint32_t per_tile = (uint32_t)FUSED_ROUNDS / a.rounds;
+    const uint64_t tile = a.t.begin / CULL_TILE + blockIdx.x / per_tile;
+    tile_base = tile * CULL_TILE;
+    const uint32_t first_round = (blockIdx.x % per_tile) * a.rounds;
+    lo = a.t.begin > tile_base ? (uint32_t)(a.t.begin - tile_base) : 0u;
+    hi = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tile_base);
+    lo = max(lo, first_round * FUSED_BLOCK);
+    hi = min(hi, (first_round + a.rounds) * FUSED_BLOCK);
+  }
   const uint64_t seg = (uint64_t)a.seg_base + blockIdx.x;  // block order is candidate order
   if (lo >= hi) {  // block-uniform
     if (CULL) segment_empty(a.c, seg);
@@ -310,13 +386,88 @@ k_propagate_classify(FusedArgs a) {
   FusedParent par_next;
   if (active(0)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, 0u, head_next);
   if (active(1)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
+  // merged top levels: thread e < anc_count looks after ancestor entry e
+  float4 *anc_world = nullptr;   // [entry][4]: the ancestors' world matrices
+  uint32_t *anc_moved = nullptr;  // [entry]: the ancestor's world matrix changes this frame
+  uint32_t anc_node = 0u, anc_info = 0u, anc_f = 0u;
+  const bool anc_live = TOP && t < top.anc_count;
+  if (TOP) {
+    extern __shared__ unsigned long long fused_dynamic_lds[];  // the cull tables come first
+    anc_world = reinterpret_cast<float4 *>(reinterpret_cast<char *>(fused_dynamic_lds) + a.top_lds_offset);
+    anc_moved = reinterpret_cast<uint32_t *>(anc_world + (size_t)a.top_anc_cap * 4u);
+    const uint32_t e = top.anc_off + min(t, max(top.anc_count, 1u) - 1u);
+    anc_node = a.top_anc_node[e];
+    anc_info = a.top_anc_info[e];
+    anc_f = a.t.flags_in[anc_live ? anc_node : 0u];
+  }
   if (active(0)) {
     fused_resolve_head(a, tile_base, lo, hi, 0u, head_next);
-    if (HAS_PARENT) fused_issue_parent(a, head_next, par_next);
-    fused_issue_body(a, tile_base, lo, hi, 0u, head_next, body_next);
+    if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
+    fused_issue_body<CULL>(a, tile_base, lo, hi, 0u, head_next, body_next);
   }
   uint32_t updated_here = 0;
-  __syncthreads();  // LDS tables cleared
+  if (TOP) {
+    // The ancestor's matrix, picked by its flags like a node's own: position /
+    // rotation / scale (in x0-x2) when its TRS changed, the local matrix when it
+    // is dirty, the stored world matrix when it is clean.
+    anc_f = anc_live ? ((anc_f | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & 0xffu : 0u;
+    const bool have_trs = a.t.pos != nullptr;
+    const bool rebuild = have_trs && (anc_f & F_DIRTY_LOCAL) != 0;
+    const bool dirty = (anc_f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
+    const uint64_t g = anc_live ? anc_node : 0u;
+    const float4 *m = (dirty ? a.t.local : a.t.world) + g * 4u;
+    float4 x0 = *(rebuild ? a.t.pos + g : m);
+    float4 x1 = *(rebuild ? a.t.quat + g : m + 1);
+    float4 x2 = *(rebuild ? a.t.scale + g : m + 2);
+    float4 x3 = m[3];
+    if (rebuild) {  // scene_compute_local_matrix (the owner of the node stores it)
+      const Mat4 rebuilt_local = local_from_trs(x0, x1, x2);
+      x0 = rebuilt_local.c[0];
+      x1 = rebuilt_local.c[1];
+      x2 = rebuilt_local.c[2];
+      x3 = rebuilt_local.c[3];
+    }
+    bool moved = dirty;
+    const uint32_t pslot = anc_info & 0xffffu;
+    const uint32_t step = anc_info >> 16;
+    __syncthreads();  // LDS tables cleared
+    // the chain, root side first: vkr_scene_update pass 2 for the ancestors
+    for (uint32_t s2 = 0; s2 < top.steps; ++s2) {  // block-uniform
+      if (anc_live && step == s2) {
+        if (pslot != 0xffffu) {
+          if (anc_moved[pslot] != 0u && !moved) {  // deferred dirty propagation
+            const float4 *l = a.t.local + g * 4u;
+            x0 = l[0];
+            x1 = l[1];
+            x2 = l[2];
+            x3 = l[3];
+            moved = true;
+          }
+          if (moved) {
+            const float4 *w = anc_world + pslot * 4u;
+            const float4 p0 = w[0], p1 = w[1], p2 = w[2], p3 = w[3];
+            const float4 y0 = mat4_mul_col(p0, p1, p2, p3, x0);
+            const float4 y1 = mat4_mul_col(p0, p1, p2, p3, x1);
+            const float4 y2 = mat4_mul_col(p0, p1, p2, p3, x2);
+            const float4 y3 = mat4_mul_col(p0, p1, p2, p3, x3);
+            x0 = y0;
+            x1 = y1;
+            x2 = y2;
+            x3 = y3;
+          }
+        }
+        float4 *w = anc_world + t * 4u;
+        w[0] = x0;
+        w[1] = x1;
+        w[2] = x2;
+        w[3] = x3;
+        anc_moved[t] = moved ? 1u : 0u;
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();  // LDS tables cleared
+  }
 
 #pragma unroll
   for (int round = 0; round < FUSED_ROUNDS; ++round) {
@@ -329,91 +480,127 @@ k_propagate_classify(FusedArgs a) {
     if (active(round + 1)) {
       fused_resolve_head(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
       // ahead of the matrices: loads return in issue order and the window is needed first
-      if (HAS_PARENT) fused_issue_parent(a, head_next, par_next);
-      fused_issue_body(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
+      if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
+      fused_issue_body<CULL>(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
     if (active(round + 2))
       fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, rbase + 2 * FUSED_BLOCK, head_after);
     if (!active(round)) continue;
 
-    // ---- transform phase -------------------------------------------------------
-    // Parents were finished by the previous level's launch. The wave's parent
-    // window arrived with the round's matrices; it is spread over the wave's
-    // stretch of LDS so that the four lanes of a node can pick one column each of
-    // their parent's world matrix.
-    if (HAS_PARENT) {
+    // ---- columns in: memory layout -> compute layout ----------------------------
+    {
+      f32x4 *in0 = reinterpret_cast<f32x4 *>(s_mat + sub_slot(0) * MAT_LDS_STRIDE + col);
+      in0[0 * 16 * MAT_LDS_STRIDE] = cur.m0;
+      in0[1 * 16 * MAT_LDS_STRIDE] = cur.m1;
+      in0[2 * 16 * MAT_LDS_STRIDE] = cur.m2;
+      in0[3 * 16 * MAT_LDS_STRIDE] = cur.m3;
+    }
+    if (HAS_PARENT && !TOP) {
       if (par.ok) s_par[t] = par.pm;
-      __builtin_amdgcn_wave_barrier();  // a wave's LDS accesses stay in order
     }
+    __builtin_amdgcn_wave_barrier();  // a wave's LDS accesses stay in order
+    // the node's local matrix when it is dirty, its stored world matrix when it is
+    // clean, position / rotation / scale in l0-l2 when hd.rebuild
+    float4 l0, l1, l2, l3;
+    {
+      const float4 *own = s_mat + t * MAT_LDS_STRIDE;
+      l0 = own[0];
+      l1 = own[1];
+      l2 = own[2];
+      l3 = own[3];
+    }
+    __builtin_amdgcn_wave_barrier();  // read before anything below reuses the slots
+
+    // ---- transform, one thread per node ------------------------------------------
+    const uint64_t node = base + t;
+    const bool valid = rbase + t >= lo && rbase + t < hi;
+    uint32_t fr = hd.f;
+    // pass 1: scene_compute_local_matrix, vkr_scene_system.c:555-561,598-602
+    if (hd.rebuild) {
+      const Mat4 rebuilt_local = local_from_trs(l0, l1, l2);
+      l0 = rebuilt_local.c[0];
+      l1 = rebuilt_local.c[1];
+      l2 = rebuilt_local.c[2];
+      l3 = rebuilt_local.c[3];
+    }
+    {
+      const unsigned long long rebuilt = __ballot(hd.rebuild);  // outside the level: never set
+      if (rebuilt != 0ull) store_matrices(s_mat, a.t.local, base, l0, l1, l2, l3, rebuilt);  // wave-uniform
+    }
+    // Parents were finished by the previous level's launch, or recomputed by this
+    // block (merged top levels).
+    uint32_t pf = 0u;  // the parent's flags | F_HAS_PARENT, 0 for a root
+    uint32_t pk = 0u;  // the parent's place in the wave's window / the block's ancestor table
+    if (TOP) {
+      if (hd.p != NO_PARENT) {
+        pk = top.par_slot + (hd.p - top.par_first);
+        pf = F_HAS_PARENT | (anc_moved[pk] != 0u ? (uint32_t)F_WORLD_UPDATED : 0u);
+      }
+    } else if (HAS_PARENT) {
+      const uint32_t pm = hd.p != NO_PARENT ? 0xffffffffu : 0u;
+      uint32_t pflag;
+      if (par.ok) {  // wave-uniform
+        pk = (hd.p - par.pmin) & 15u;
+        pflag = (uint32_t)__shfl((int)par.pf, (int)pk, 64);
+      } else {
+        pflag = a.t.flags_out[hd.p & pm];  // roots read node 0 and drop the result
+      }
+      pf = ((pflag & 0x7fu) | F_HAS_PARENT) & pm & 0xffu;
+    }
+    // deferred dirty propagation, vkr_scene_system.c:1310-1316
+    if (HAS_PARENT && valid && (pf & F_WORLD_UPDATED) && !(fr & F_DIRTY_WORLD)) {
+      const float4 *l = a.t.local + node * 4u;  // the parent moved: this node moves too
+      l0 = l[0];
+      l1 = l[1];
+      l2 = l[2];
+      l3 = l[3];
+      fr |= F_DIRTY_WORLD;
+    }
+    bool did_update = false;
+    if (fr & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
+      did_update = true;
+      fr = (fr & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
+    }
+    float4 w0 = l0, w1 = l1, w2 = l2, w3 = l3;
+    if (HAS_PARENT && did_update && (pf & F_HAS_PARENT)) {  // mat4_mul(parent.world, local)
+      // one column of the parent's matrix at a time (see mat4_mul_step); a loop per
+      // source, so that each load knows its address space
+      auto times_local = [&](const float4 *parent_world) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t slot = sub_slot(r);
-      const uint64_t node = base + slot;
-      const bool valid = rbase + slot >= lo && rbase + slot < hi;
-      uint32_t fr = hd.f(r);
-      float4 lcol = cur.m[r];
-      if (hd.rebuild & (1u << r)) {  // the same for the four lanes of the node
-        lcol = local_col_from_quad(lcol, col);
-        if (valid) a.t.local[node * 4u + col] = lcol;
-      }
-      float4 pcr = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t pf = 0u;  // the parent's flags | F_HAS_PARENT, 0 for a root
-      if (HAS_PARENT) {
-        // the parent index sits in the lane that loaded it for the cull mapping
-        const uint32_t par_node = (uint32_t)__shfl((int)hd.p, r * 16 + (int)((t & 63u) >> 2), 64);
-        const uint32_t pm = par_node != NO_PARENT ? 0xffffffffu : 0u;
-        uint32_t pflag;
-        if (par.ok) {  // wave-uniform
-          const uint32_t k = (par_node - par.pmin) & 15u;
-          pcr = s_par[(t & ~63u) + k * 4u + col];
-          pflag = (uint32_t)__shfl((int)par.pf, (int)k, 64);
-        } else {
-          const uint64_t pidx = par_node & pm;  // roots read node 0 and drop the result
-          pcr = a.t.world[pidx * 4u + col];
-          pflag = a.t.flags[pidx];
+        for (int k = 0; k < 4; ++k) {
+          const float4 pcol = parent_world[k];
+          mat4_mul_step(k, pcol, l0, w0);
+          mat4_mul_step(k, pcol, l1, w1);
+          mat4_mul_step(k, pcol, l2, w2);
+          mat4_mul_step(k, pcol, l3, w3);
         }
-        pf = ((pflag & 0x7fu) | F_HAS_PARENT) & pm & 0xffu;
+      };
+      if (TOP) {
+        times_local(anc_world + pk * 4u);
+      } else if (par.ok) {  // wave-uniform
+        times_local(s_par + (t & ~63u) + pk * 4u);
+      } else {
+        times_local(a.t.world + (uint64_t)hd.p * 4u);
       }
-      // deferred dirty propagation, vkr_scene_system.c:1310-1316
-      if (HAS_PARENT && valid && (pf & F_WORLD_UPDATED) && !(fr & F_DIRTY_WORLD)) {
-        lcol = a.t.local[node * 4u + col];  // the parent moved: this node moves too
-        fr |= F_DIRTY_WORLD;
-      }
-      float4 wcol = lcol;
-      bool did_update = false;
-      if (fr & F_DIRTY_WORLD) {  // pass 2, vkr_scene_system.c:1319-1336
-        did_update = true;
-        fr = (fr & ~(uint32_t)F_DIRTY_WORLD) | F_WORLD_UPDATED;
-      }
-      if (HAS_PARENT) {
-        // all four lanes of the node take part in the column exchange
-        const float4 a0 = quad_bcast4<0>(pcr);
-        const float4 a1 = quad_bcast4<1>(pcr);
-        const float4 a2 = quad_bcast4<2>(pcr);
-        const float4 a3 = quad_bcast4<3>(pcr);
-        if (did_update && (pf & F_HAS_PARENT)) wcol = mat4_mul_col(a0, a1, a2, a3, lcol);
-      }
-      if (did_update) a.t.world[node * 4u + col] = wcol;
-      if (valid && col == 0) a.t.flags[node] = (uint8_t)fr;
-      if (CULL) s_mat[slot * MAT_LDS_STRIDE + col] = wcol;
-      updated_here += (did_update && col == 0) ? 1u : 0u;  // per lane; summed when the block ends
     }
+    if (valid) *at32(a.t.flags_out + base, t) = (uint8_t)fr;
+    {
+      const unsigned long long moved = __ballot(did_update);
+      if (moved != 0ull) store_matrices(s_mat, a.t.world, base, w0, w1, w2, w3, moved);  // wave-uniform
+    }
+    updated_here += did_update ? 1u : 0u;  // per lane; summed when the block ends
     if (!CULL) continue;  // transform only
-    __builtin_amdgcn_wave_barrier();  // the wave's own columns: LDS keeps a wave's accesses in order
 
     // ---- cull phase ------------------------------------------------------------
-    Mat4 m;
-    {
-      const float4 *p = s_mat + t * MAT_LDS_STRIDE;
-      m.c[0] = p[0];
-      m.c[1] = p[1];
-      m.c[2] = p[2];
-      m.c[3] = p[3];
-    }
-    __builtin_amdgcn_wave_barrier();  // read before the next round overwrites the slots
-    const bool cvalid = rbase + t >= lo && rbase + t < hi && base + t < a.c.n;
-    packed |= classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, m,
-                                                   hd.ls, hd.cf)
+    const bool cvalid = valid && base + t < a.c.n;
+    const uint32_t cf = cvalid ? hd.cf : 0xf0u;  // invalid bucket: fails every gate
+    Mat4 world;
+    world.c[0] = w0;
+    world.c[1] = w1;
+    world.c[2] = w2;
+    world.c[3] = w3;
+    packed |= classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, world,
+                                                   make_float4(hd.ls.x, hd.ls.y, hd.ls.z, hd.ls.w), cf)
               << (8 * round);
   }
   {

@@ -28,7 +28,8 @@ struct TransformArgs {
   const float4 *scale;
   float4 *local;  // 4 float4 per node
   float4 *world;
-  uint8_t *flags;
+  const uint8_t *flags_in;  // the nodes' flags before the frame
+  uint8_t *flags_out;       // ... and after it (another buffer: the host swaps the two)
   uint32_t *counters;  // sharded frame counters; blocks add to NODES_UPDATED of their shard
   uint64_t begin;  // level range [begin, end)
   uint64_t end;

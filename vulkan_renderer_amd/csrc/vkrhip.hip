@@ -62,7 +62,23 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> parent;
   DevBuf<float4> pos, quat, scale;  // lazily allocated
   DevBuf<float4> local, world;
-  DevBuf<uint8_t> flags;
+  // SceneTransform.flags, held twice: a frame reads the nodes' flags from one copy
+  // and writes the updated flags to the other, so that blocks which recompute
+  // their ancestors (the merged top levels) see the flags as they were before the
+  // frame whatever the owners of those nodes have already written. flags_cur names
+  // the copy that holds the current state.
+  DevBuf<uint8_t> flags2[2];
+  uint32_t flags_cur = 0;
+  uint8_t *flags() const { return flags2[flags_cur].p; }
+  uint8_t *flags_other() const { return flags2[flags_cur ^ 1u].p; }
+  // Merged top levels (see TopPlan in k_fused.hpp): levels [0, top_levels) run as
+  // ONE launch whose blocks recompute their ancestors; 0 = every level its own launch.
+  uint32_t top_levels = 0;
+  uint32_t top_blocks = 0;
+  uint32_t top_anc_cap = 0;  // largest ancestor count of a block (rounded up to 64)
+  DevBuf<TopDesc> top_desc;
+  DevBuf<uint32_t> top_anc_node, top_anc_info;
+  bool top_enabled = true;  // VKRHIP_TOP_LEVELS=0 switches the merged launch off (A/B runs)
   uint32_t force_flags = 0;
   uint32_t fused_rounds = 0;  // tuning override (VKRHIP_FUSED_ROUNDS = 1, 2 or 4); 0 = by level size
   bool have_trs = false;
@@ -401,6 +417,117 @@ int check_range(vkrhip_ctx *c, uint64_t first, uint64_t count, uint64_t limit, c
   return VKRHIP_OK;
 }
 
+
+// Plan of the merged top levels. The first levels of a hierarchy hold few
+// nodes; a launch per level spends most of its time on the chain of dependent
+// cold loads of one block. Instead ONE launch covers levels [0, K): a block
+// (one 1024-node tile of one level) first recomputes the world matrices of its
+// nodes' ancestors - from the same inputs, with the same operations in the same
+// order as their owners, so bit for bit the same values - and therefore waits
+// for no other block. In BFS order the ancestors of a tile are a short
+// contiguous range per level; this builds the tables (per block: that range
+// list flattened to one entry per ancestor, root side first). Hierarchies
+// whose ranges are wide (parents not ascending with their children) get no
+// plan and run a launch per level.
+constexpr uint32_t kTopMaxTiles = 1024;     // the merged launch covers at most this many tiles
+constexpr uint32_t kTopMaxAncestors = TOP_MAX_ANCESTORS;
+constexpr uint32_t kTopMaxSteps = 24;
+
+struct TopPlanHost {
+  uint32_t levels = 0;
+  uint32_t anc_cap = 0;
+  std::vector<TopDesc> desc;
+  std::vector<uint32_t> anc_node, anc_info;
+};
+
+TopPlanHost build_top_plan(const uint32_t *parent, const std::vector<uint64_t> &lo, uint32_t levels) {
+  TopPlanHost plan;
+  if (!parent || levels < 2) return plan;
+  // how many levels fit the tile budget
+  uint32_t k = 0;
+  uint64_t tiles = 0;
+  while (k < levels) {
+    const uint64_t b = lo[k], e = lo[k + 1];
+    const uint64_t t = e > b ? ceil_div(e, CULL_TILE) - b / CULL_TILE : 0;
+    if (tiles + t > kTopMaxTiles) break;
+    tiles += t;
+    ++k;
+  }
+  if (k < 2) return plan;  // nothing to merge
+  struct Range {
+    uint32_t first, count;
+  };
+  for (uint32_t l = 0; l < k; ++l) {
+    const uint64_t b = lo[l], e = lo[l + 1];
+    if (e == b) continue;
+    // a block per ROUND of a tile (256 nodes): the levels are small, so many short
+    // blocks hide one another's load latency better than a few long ones
+    for (uint64_t chunk = b / FUSED_BLOCK; chunk < ceil_div(e, FUSED_BLOCK); ++chunk) {
+      const uint64_t tile_base = chunk * FUSED_BLOCK / CULL_TILE * CULL_TILE;
+      const uint64_t nb = std::max<uint64_t>(b, chunk * FUSED_BLOCK);
+      const uint64_t ne = std::min<uint64_t>(e, (chunk + 1) * FUSED_BLOCK);
+      // ranges of ancestors, nearest level first
+      std::vector<Range> chain;
+      uint64_t rb = nb, re = ne;
+      for (;;) {
+        uint32_t pmin = VKRHIP_NO_PARENT, pmax = 0;
+        for (uint64_t i = rb; i < re; ++i) {
+          const uint32_t p = parent[i];
+          if (p == VKRHIP_NO_PARENT) continue;
+          pmin = std::min(pmin, p);
+          pmax = std::max(pmax, p);
+        }
+        if (pmin == VKRHIP_NO_PARENT) break;  // only roots left
+        // a range must stay inside one level, above the level it was derived from:
+        // its nodes are recomputed side by side in one step of the chain
+        const size_t lvl = (size_t)(std::upper_bound(lo.begin(), lo.end(), (uint64_t)pmin) - lo.begin()) - 1u;
+        if ((uint64_t)pmax >= lo[lvl + 1] || lo[lvl + 1] > rb) return TopPlanHost();
+        chain.push_back({pmin, pmax - pmin + 1u});
+        if (chain.size() > kTopMaxSteps) return TopPlanHost();
+        rb = pmin;
+        re = (uint64_t)pmax + 1u;
+      }
+      uint64_t total = 0;
+      for (const Range &r : chain) total += r.count;
+      if (total > kTopMaxAncestors) return TopPlanHost();
+      TopDesc d{};
+      d.tile_base = (uint32_t)tile_base;
+      d.lo_hi = (uint32_t)(nb - tile_base) | ((uint32_t)(ne - tile_base) << 16);
+      d.anc_off = (uint32_t)plan.anc_node.size();
+      d.anc_count = (uint32_t)total;
+      d.steps = (uint32_t)chain.size();
+      // root side first: step s holds chain[steps - 1 - s]
+      std::vector<uint32_t> slot_base(chain.size());
+      uint32_t slot = 0;
+      for (size_t s2 = 0; s2 < chain.size(); ++s2) {
+        slot_base[chain.size() - 1 - s2] = slot;
+        slot += chain[chain.size() - 1 - s2].count;
+      }
+      for (size_t s2 = 0; s2 < chain.size(); ++s2) {
+        const size_t ci = chain.size() - 1 - s2;  // index into chain (0 = the parents' level)
+        const Range &r = chain[ci];
+        for (uint32_t j = 0; j < r.count; ++j) {
+          const uint32_t g = r.first + j;
+          const uint32_t p = parent[g];
+          uint32_t pslot = 0xffffu;
+          if (p != VKRHIP_NO_PARENT) pslot = slot_base[ci + 1] + (p - chain[ci + 1].first);
+          plan.anc_node.push_back(g);
+          plan.anc_info.push_back(pslot | ((uint32_t)s2 << 16));
+        }
+      }
+      if (!chain.empty()) {
+        d.par_first = chain[0].first;
+        d.par_slot = slot_base[0];
+      }
+      plan.anc_cap = std::max(plan.anc_cap, (uint32_t)total);
+      plan.desc.push_back(d);
+    }
+  }
+  plan.levels = k;
+  plan.anc_cap = (plan.anc_cap + 63u) & ~63u;
+  return plan;
+}
+
 }  // namespace
 
 extern "C" {
@@ -433,6 +560,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     const int r = std::atoi(env);
     if (r == 1 || r == 2 || r == 4) c->fused_rounds = (uint32_t)r;
   }
+  if (const char *env = std::getenv("VKRHIP_TOP_LEVELS")) c->top_enabled = std::atoi(env) != 0;
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
@@ -442,8 +570,10 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
     TRY(dev_alloc(c, c->local, mn * 4));
     TRY(dev_alloc(c, c->world, mn * 4));
-    TRY(dev_alloc(c, c->flags, mn + 16));
-    HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, mn + 16, c->stream));
+    for (auto &f : c->flags2) {
+      TRY(dev_alloc(c, f, mn + 16));
+      HIP_TRY(c, hipMemsetAsync(f.p, 0, mn + 16, c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(c->world.p, 0, mn * 64, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->local.p, 0, mn * 64, c->stream));
     TRY(dev_alloc(c, c->ident, mc * 2));
@@ -498,7 +628,11 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->scale);
   dev_free(c->local);
   dev_free(c->world);
-  dev_free(c->flags);
+  dev_free(c->flags2[0]);
+  dev_free(c->flags2[1]);
+  dev_free(c->top_desc);
+  dev_free(c->top_anc_node);
+  dev_free(c->top_anc_info);
   dev_free(c->node);
   dev_free(c->ident);
   dev_free(c->sphere);
@@ -624,6 +758,28 @@ int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes
   }
   c->n_nodes = n_nodes;
   c->level_offsets = lo;
+  c->top_levels = 0;
+  c->top_blocks = 0;
+  if (c->top_enabled && n_nodes) {
+    const TopPlanHost plan = build_top_plan(parent, lo, levels);
+    if (plan.levels) {
+      TRY(dev_alloc(c, c->top_desc, plan.desc.size()));
+      TRY(dev_alloc(c, c->top_anc_node, std::max<size_t>(plan.anc_node.size(), 1)));
+      TRY(dev_alloc(c, c->top_anc_info, std::max<size_t>(plan.anc_info.size(), 1)));
+      HIP_TRY(c, hipMemcpyAsync(c->top_desc.p, plan.desc.data(), plan.desc.size() * sizeof(TopDesc),
+                                hipMemcpyHostToDevice, c->stream));
+      if (!plan.anc_node.empty()) {
+        HIP_TRY(c, hipMemcpyAsync(c->top_anc_node.p, plan.anc_node.data(), plan.anc_node.size() * 4,
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->top_anc_info.p, plan.anc_info.data(), plan.anc_info.size() * 4,
+                                  hipMemcpyHostToDevice, c->stream));
+      }
+      HIP_TRY(c, hipStreamSynchronize(c->stream));  // the plan's vectors go out of scope
+      c->top_levels = plan.levels;
+      c->top_blocks = (uint32_t)plan.desc.size();
+      c->top_anc_cap = plan.anc_cap;
+    }
+  }
   return VKRHIP_OK;
 } catch (...) {
   return host_exception(c);
@@ -644,10 +800,13 @@ int vkrhip_upload_trs(vkrhip_ctx *c, uint64_t first, uint64_t count, const float
   HIP_TRY(c, hipMemcpyAsync(c->scale.p + first, scale4, count * 16, hipMemcpyHostToDevice, c->stream));
   // transform setters set DIRTY_LOCAL (vkr_scene_system.h:70-72)
   std::vector<uint8_t> f(count);
-  HIP_TRY(c, hipMemcpyAsync(f.data(), c->flags.p + first, count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(f.data(), c->flags() + first, count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (auto &x : f) x |= VKRHIP_DIRTY_LOCAL;
-  HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
+  // into both copies: nodes outside the bound hierarchy are not rewritten by a frame
+  // and must read the same whichever copy is current
+  for (auto &b : c->flags2)
+    HIP_TRY(c, hipMemcpyAsync(b.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
 } catch (...) {
@@ -662,10 +821,11 @@ int vkrhip_upload_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, const fl
   HIP_TRY(c, hipMemcpyAsync(c->local.p + first * 4, local16, count * 64, hipMemcpyHostToDevice,
                             c->stream));
   std::vector<uint8_t> f(count);
-  HIP_TRY(c, hipMemcpyAsync(f.data(), c->flags.p + first, count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(f.data(), c->flags() + first, count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (auto &x : f) x |= VKRHIP_DIRTY_WORLD;
-  HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
+  for (auto &b : c->flags2)
+    HIP_TRY(c, hipMemcpyAsync(b.p + first, f.data(), count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
 } catch (...) {
@@ -688,7 +848,8 @@ int vkrhip_upload_node_flags(vkrhip_ctx *c, uint64_t first, uint64_t count, cons
   TRY(check_range(c, first, count, c->cfg.max_nodes, "upload_node_flags"));
   if (count == 0) return VKRHIP_OK;
   TRY(bind_device(c));
-  HIP_TRY(c, hipMemcpyAsync(c->flags.p + first, flags, count, hipMemcpyHostToDevice, c->stream));
+  for (auto &b : c->flags2)
+    HIP_TRY(c, hipMemcpyAsync(b.p + first, flags, count, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
 }
@@ -948,7 +1109,8 @@ static TransformArgs transform_args(vkrhip_ctx *c, uint32_t level) {
   a.scale = c->scale.p;
   a.local = c->local.p;
   a.world = c->world.p;
-  a.flags = c->flags.p;
+  a.flags_in = c->flags();
+  a.flags_out = c->flags_other();
   a.counters = c->counters();
   a.begin = c->level_offsets[level];
   a.end = c->level_offsets[level + 1];
@@ -992,11 +1154,37 @@ static CullArgs cull_args(vkrhip_ctx *c) {
 
 static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *rounds);
 
+// The merged launch of the top levels: ancestor tables, dynamic LDS behind the
+// cull tables.
+static size_t top_lds_bytes(const vkrhip_ctx *c) {
+  return (size_t)c->top_anc_cap * (64u + 4u);
+}
+static void top_args(vkrhip_ctx *c, FusedArgs &a, size_t cull_lds) {
+  a.t = transform_args(c, 0);
+  a.t.begin = 0;
+  a.t.end = c->level_offsets[c->top_levels];
+  a.rounds = FUSED_ROUNDS;
+  a.top = c->top_desc.p;
+  a.top_anc_node = c->top_anc_node.p;
+  a.top_anc_info = c->top_anc_info.p;
+  a.top_lds_offset = (uint32_t)((cull_lds + 15u) & ~(size_t)15u);
+  a.top_anc_cap = c->top_anc_cap;
+}
+
 // Transform only: the fused kernel without its cull phase.
 static int launch_transform(vkrhip_ctx *c) {
   bool first = true;
   const uint32_t levels = c->level_offsets.empty() ? 0u : (uint32_t)c->level_offsets.size() - 1u;
-  for (uint32_t l = 0; l < levels; ++l) {
+  uint32_t l0 = 0;
+  if (c->top_levels && c->parent.p) {
+    FusedArgs a{};
+    top_args(c, a, 0);
+    launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<true, false, false, false, true>,
+                 dim3(c->top_blocks), dim3(FUSED_BLOCK), a.top_lds_offset + top_lds_bytes(c), a);
+    first = false;
+    l0 = c->top_levels;
+  }
+  for (uint32_t l = l0; l < levels; ++l) {
     FusedArgs a{};
     const uint64_t grid = fused_level_grid(c, l, &a.rounds);
     if (!grid) continue;
@@ -1010,6 +1198,7 @@ static int launch_transform(vkrhip_ctx *c) {
     first = false;
   }
   c->force_flags = 0;
+  if (!first) c->flags_cur ^= 1u;  // the launches wrote every node's flags to the other copy
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
@@ -1043,29 +1232,31 @@ static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *roun
   return tiles * (FUSED_ROUNDS / *rounds);
 }
 
-template <bool HAS_PARENT>
+template <bool HAS_PARENT, bool TOP = false>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
                                  bool bounds_out, bool first) {
   const dim3 g(grid), b(FUSED_BLOCK);
-  const size_t lds = cull_shared_bytes(a.c.views);
+  const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c) : cull_shared_bytes(a.c.views);
   if (ties) {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP>, g, b, lds, a);
   } else {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP>, g, b, lds, a);
   }
 }
 
-// Transform and classify in one launch per level (candidate i <-> node i).
+// Transform and classify in one launch per level (candidate i <-> node i); the
+// small top levels of a hierarchy share one launch when a plan exists.
 static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
   const uint32_t levels = (uint32_t)c->level_offsets.size() - 1u;
-  uint64_t segments = 0;
-  for (uint32_t l = 0; l < levels; ++l) {
+  const uint32_t l0 = c->top_levels && c->parent.p ? c->top_levels : 0u;
+  uint64_t segments = l0 ? c->top_blocks : 0u;
+  for (uint32_t l = l0; l < levels; ++l) {
     uint32_t rounds = 4;
     segments += fused_level_grid(c, l, &rounds);
   }
@@ -1073,7 +1264,16 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
   bool first = true;
   const bool ties = c->cfg.tie_epsilon > 0.f;
   uint64_t seg_base = 0;
-  for (uint32_t l = 0; l < levels; ++l) {
+  if (l0) {
+    FusedArgs a{};
+    a.c = cull_args(c);
+    top_args(c, a, cull_shared_bytes(c->views));
+    a.seg_base = 0;
+    launch_fused_variant<true, true>(c, a, c->top_blocks, ties, bounds_out, first);
+    first = false;
+    seg_base = c->top_blocks;
+  }
+  for (uint32_t l = l0; l < levels; ++l) {
     FusedArgs a{};
     const uint64_t grid = fused_level_grid(c, l, &a.rounds);
     if (!grid) continue;
@@ -1089,6 +1289,7 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
   }
   c->segments = segments;
   c->force_flags = 0;
+  if (!first) c->flags_cur ^= 1u;  // the launches wrote every node's flags to the other copy
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
@@ -1393,7 +1594,7 @@ int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   if (!c || !out) return VKRHIP_ERR_ARG;
   std::memset(out, 0, sizeof(*out));
   out->world = reinterpret_cast<const float *>(c->world.p);
-  out->node_flags = c->flags.p;
+  out->node_flags = c->flags();
   out->visible = c->visible.p;
   out->visible_stride = c->visible_stride;
   out->transparent_visible = c->tvis.p;
@@ -1438,7 +1639,7 @@ int vkrhip_read_locals(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out
 int vkrhip_read_node_flags(vkrhip_ctx *c, uint64_t first, uint64_t count, uint8_t *out) {
   if (!c || !out) return VKRHIP_ERR_ARG;
   TRY(check_range(c, first, count, c->cfg.max_nodes, "read_node_flags"));
-  return read_back(c, out, c->flags.p + first, count);
+  return read_back(c, out, c->flags() + first, count);
 }
 
 int vkrhip_read_visible(vkrhip_ctx *c, uint32_t view, uint64_t count, uint32_t *out) {
