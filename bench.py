@@ -8,9 +8,12 @@ already resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-Workloads: flat1m (1M instances, flat, one view; the default), deep16m (16M,
-depth-8 hierarchy, camera + 4 cascades), flat32m (the per-GPU shard of 256M over
-eight GPUs), probes64 (16M, 64 views).
+Workloads: deep16m (16M instances, depth-8 hierarchy, camera + 4 cascades: the
+default, the largest single-GPU configuration), flat1m (1M, flat, one view),
+flat32m (the per-GPU shard of 256M over eight GPUs), probes64 (16M, 64 views).
+With one GPU the line also carries `secondary` (the other workloads, shorter
+runs, each with its own roofline) and `dropin` (the frame with the 144-byte
+candidate rows, with and without the host copies a host-side consumer needs).
 With N > 1 every rank owns a contiguous shard of the same size (weak scaling)
 and the per-frame exchange all-gathers the visible lists and merges the sorted
 draw-key runs.
@@ -86,9 +89,10 @@ def pmc_traffic(workload_name: str, overridden: bool, kernel: str, variant=None)
         data = json.load(fh)
     total = 0.0
     for name, k in data["kernels"].items():
-        # the last template argument of k_propagate_classify tells the fused kernel
+        # the fourth template argument of k_propagate_classify tells the fused kernel
         # (true) from its transform-only variant (false)
-        if name.startswith(kernel) and (variant is None or name.rstrip().endswith(variant + ">")):
+        targs = [x.strip() for x in name[name.find("<") + 1: name.rfind(">")].split(",")] if "<" in name else []
+        if name.startswith(kernel) and (variant is None or (len(targs) > 3 and targs[3] == variant)):
             total += k["dispatches_per_frame"] * (k["fetch_bytes_per_dispatch_x2"] +
                                                   k["write_bytes_per_dispatch"])
     return (total or None), os.path.relpath(paths[-1], ROOT)
@@ -113,12 +117,171 @@ def build_scene(workload: dict, rank: int, seed: int, submeshes: int = 1):
     return sc, vs, extra
 
 
+class Setup:
+    """One workload resident in HBM: scene, views, context."""
+
+    def __init__(self, name, workload, rank, local_rank, seed, submeshes):
+        import torch
+        from vulkan_renderer_amd import HipScene, build_view_set, frustum_from_matrix
+        from vulkan_renderer_amd import _native as N
+        self.name, self.workload = name, workload
+        sc, vs, extra = build_scene(workload, rank, seed, submeshes)
+        n = sc.ident.shape[0]
+        planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
+        if extra is not None:
+            planes = np.concatenate([planes, np.stack([frustum_from_matrix(m) for m in extra])])
+            required = np.concatenate([required, np.full(len(extra), N.CAND_SHADOW_CASTER, np.uint32)])
+        self.sc, self.vs, self.planes, self.required, self.n = sc, vs, planes, required, n
+        self.views = planes.shape[0]
+        hs = HipScene(max_nodes=sc.n, max_candidates=n, max_views=self.views, device=local_rank,
+                      source_index_base=rank * n)
+        hs.set_stream(torch.cuda.current_stream().cuda_stream)
+        hs.set_hierarchy(sc.parent if workload["depth"] > 1 else None, sc.level_offsets)
+        hs.upload_trs(sc.pos, sc.quat, sc.scale)
+        hs.set_candidates(sc.node if submeshes > 1 else None, sc.ident, sc.matbits, sc.bounds)
+        hs.set_views(planes, required, vs.view)
+        hs.frame(N.STAGE_TRANSFORM)  # materialise local matrices from TRS once (not timed)
+        hs.sync()
+        self.hs = hs
+
+    def close(self):
+        self.hs.close()
+
+
+def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden):
+    """Timed frames of one workload. Returns (elapsed seconds, roofline dict, warm-up
+    stage timings, frame info)."""
+    from vulkan_renderer_amd import _native as N
+    hs, sc, workload, n = setup.hs, setup.sc, setup.workload, setup.n
+    dirty_bits = N.DIRTY_LOCAL if dirty == "local" else N.DIRTY_WORLD
+
+    def step():
+        hs.mark_all(dirty_bits)      # every node moved this frame
+        hs.frame(N.STAGE_ALL)
+        if exchange is not None:
+            exchange.run()
+
+    # warm-up, also used to find the dominant kernel
+    hs.set_profiling(True)
+    for _ in range(max(warmup, 1)):
+        step()
+        if exchange is not None:
+            exchange.finish()        # sizes the exchange blocks (same decision on every rank)
+    fence()
+    warm = hs.timers(reset=True)
+    dominant = max(("transform", "classify", "fused"), key=lambda k: warm[k][0])
+
+    # The dominant kernel is timed with HIP events on the library's stream (an
+    # event pair attached to each of its launches, i.e. the kernel's own start and
+    # end) in one of every EVENT_STRIDE timed steps: the timestamped launches cost
+    # a few microseconds of queue time, which is visible at short frame lengths.
+    hs.set_profiling(False)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        sampled = k % EVENT_STRIDE == 0
+        if sampled:
+            hs.set_profiling([dominant])
+        step()
+        if sampled:
+            hs.set_profiling(False)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timers = hs.timers(reset=True)
+    info = hs.frame_info()
+
+    dom_ms, dom_n = timers[dominant]
+    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
+    survivors = sum(st.visible_count for st in info.views) + info.transparent_draw_count
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors, dirty == "local", submeshes)
+    achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+    traffic, traffic_source = pmc_traffic(setup.name, overridden, KERNEL_NAMES[dominant],
+                                          {"fused": "true", "transform": "false"}.get(dominant))
+    roofline = {
+        "bound": "hbm", "kernel": KERNEL_NAMES[dominant],
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_source,
+        "launch": "all launches of the kernel in one step (the merged top levels, then one per "
+                  "remaining hierarchy level) taken as one",
+        "avg_launch_us": round(dom_avg_s * 1e6, 2), "event_samples": dom_n,
+        "algorithmic_bytes_per_step": int(alg_bytes),
+    }
+    stage_us = {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in warm.items() if v[1]}
+    return elapsed, roofline, stage_us, info
+
+
+CANDIDATE_ROW_BYTES = 144            # VkrWorldDrawCandidate
+CANDIDATE_IN_BYTES = 64 + 32 + 16 + 4  # world matrix, identity words, local sphere, candidate word
+
+
+def measure_dropin(setup, steps, fence) -> dict:
+    """The frame a drop-in behind application_build_world_payload runs: the timed
+    stages plus the 144-byte VkrWorldDrawCandidate rows of every source row
+    (STAGE_CANDIDATES), once with the outputs left in HBM (a backend that consumes
+    device memory) and once with the host copies the Vulkan backend wants: frame
+    counters, candidate rows, sorted draws and instances."""
+    import ctypes as C
+    from vulkan_renderer_amd import _native as N
+    hs, n = setup.hs, setup.n
+    lib = hs.lib
+    stages = N.STAGE_ALL | N.STAGE_CANDIDATES
+
+    def frame():
+        hs.mark_all(N.DIRTY_WORLD)
+        hs.frame(stages)
+
+    frame()
+    fence()
+    hs.set_profiling(["candidates"])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    fence()
+    device_s = (time.perf_counter() - t0) / steps
+    cand_ms, cand_n = hs.timers(reset=True)["candidates"]
+    hs.set_profiling(False)
+    cand_s = cand_ms * 1e-3 / max(cand_n, 1)
+
+    info = hs.frame_info()
+    t = info.transparent_draw_count
+    rows = np.empty(n * CANDIDATE_ROW_BYTES, np.uint8)
+    draws = np.empty(max(t, 1) * 48, np.uint8)
+    inst = np.empty(max(t, 1) * 80, np.uint8)
+    raw = N.FrameInfo()
+    host_steps = max(1, min(steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(host_steps):
+        frame()
+        hs._ok(lib.vkrhip_get_frame_info(hs.ctx, C.byref(raw)))   # waits for the frame
+        hs._ok(lib.vkrhip_read_candidates(hs.ctx, 0, n, N.ptr(rows)))
+        hs._ok(lib.vkrhip_read_transparent(hs.ctx, raw.transparent_draw_count, N.ptr(draws),
+                                           N.ptr(inst), None, None))
+    host_s = (time.perf_counter() - t0) / host_steps
+    emit_bytes = n * (CANDIDATE_IN_BYTES + CANDIDATE_ROW_BYTES)
+    return {
+        "stages": "transform + cull + sort + 144-byte candidate rows (STAGE_ALL | STAGE_CANDIDATES)",
+        "ms_per_step": device_s * 1e3, "value": n / device_s,
+        "ms_per_step_with_host_copies": host_s * 1e3, "value_with_host_copies": n / host_s,
+        "host_copies": f"frame counters, {n} candidate rows ({n * CANDIDATE_ROW_BYTES / 1e6:.0f} MB), "
+                       f"{t} sorted draws + instances into pageable host memory, every frame "
+                       "(the reference caps a frame at 262144 rows = 38 MB)",
+        "roofline_emit_candidates": {
+            "bound": "hbm", "kernel": "k_emit_candidates", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "achieved": round(emit_bytes / cand_s / 1e9, 1) if cand_s > 0 else 0.0,
+            "frac": round(emit_bytes / cand_s / 1e9 / HBM_PEAK_GBS, 4) if cand_s > 0 else 0.0,
+            "avg_launch_us": round(cand_s * 1e6, 2),
+            "algorithmic_bytes_per_step": int(emit_bytes),
+        },
+    }
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="flat1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="deep16m", choices=sorted(WORKLOADS))
     ap.add_argument("--instances", type=int, default=0, help="override instances per GPU")
     ap.add_argument("--depth", type=int, default=-1, help="override hierarchy depth")
     ap.add_argument("--cascades", type=int, default=-1, help="override shadow cascade count")
@@ -130,6 +293,10 @@ def main() -> int:
                     help="what moves every frame: world = cached local matrices are re-propagated "
                          "(default); local = every node's TRS changed, locals are rebuilt too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other single-GPU workloads (flat1m, flat32m, probes64)")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the drop-in frame (candidate rows + host copies)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend; gloo lets several ranks rehearse on one GPU")
@@ -168,9 +335,7 @@ def main() -> int:
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from vulkan_renderer_amd import HipScene, build_view_set, frustum_from_matrix
-    from vulkan_renderer_amd import _native as N
-    from vulkan_renderer_amd.parallel import RcclExchange, ShardExchange
+    from vulkan_renderer_amd.parallel import ExchangeOverflow, RcclExchange, ShardExchange
 
     workload = dict(WORKLOADS[args.workload])
     if args.instances:
@@ -178,25 +343,10 @@ def main() -> int:
     for key in ("depth", "cascades", "probes"):
         if getattr(args, key) >= 0:
             workload[key] = getattr(args, key)
-    n = workload["n"]
-    sc, vs, extra = build_scene(workload, rank, args.seed, args.submeshes)
-    n = sc.ident.shape[0]
-    planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
-    if extra is not None:
-        planes = np.concatenate([planes, np.stack([frustum_from_matrix(m) for m in extra])])
-        required = np.concatenate([required, np.full(len(extra), N.CAND_SHADOW_CASTER, np.uint32)])
-    views = planes.shape[0]
-
-    hs = HipScene(max_nodes=sc.n, max_candidates=n, max_views=views, device=local_rank,
-                  source_index_base=rank * n)
-    stream = torch.cuda.current_stream()
-    hs.set_stream(stream.cuda_stream)
-    hs.set_hierarchy(sc.parent if workload["depth"] > 1 else None, sc.level_offsets)
-    hs.upload_trs(sc.pos, sc.quat, sc.scale)
-    hs.set_candidates(sc.node if args.submeshes > 1 else None, sc.ident, sc.matbits, sc.bounds)
-    hs.set_views(planes, required, vs.view)
-    hs.frame(N.STAGE_TRANSFORM)  # materialise local matrices from TRS once (not timed)
-    hs.sync()
+    overridden = (bool(args.instances) or args.dirty != "world" or args.submeshes != 1 or
+                  any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes")))
+    setup = Setup(args.workload, workload, rank, local_rank, args.seed, args.submeshes)
+    hs, sc, n, views = setup.hs, setup.sc, setup.n, setup.views
     exchange = None
     if world > 1 or args.exchange:
         # the library's own RCCL exchange; the torch collective only for the gloo rehearsal
@@ -216,55 +366,25 @@ def main() -> int:
         if not native:
             exchange = ShardExchange(hs, world, rank, views)
 
-    dirty_bits = N.DIRTY_LOCAL if args.dirty == "local" else N.DIRTY_WORLD
-
-    def step():
-        hs.mark_all(dirty_bits)      # every node moved this frame
-        hs.frame(N.STAGE_ALL)
-        if exchange is not None:
-            exchange.run()
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up, also used to find the dominant kernel
-    hs.set_profiling(True)
-    for _ in range(max(args.warmup, 1)):
-        step()
-        if exchange is not None:
-            exchange.finish()        # sizes the exchange blocks (same decision on every rank)
-    fence()
-    warm = hs.timers(reset=True)
-    dominant = max(("transform", "classify", "fused"), key=lambda k: warm[k][0])
-
-    # The dominant kernel is timed with HIP events on the library's stream (an
-    # event pair attached to each of its launches, i.e. the kernel's own start and
-    # end) in one of every EVENT_STRIDE timed steps: the timestamped launches cost
-    # a few microseconds of queue time, which is visible at this frame length.
-    hs.set_profiling(False)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        sampled = k % EVENT_STRIDE == 0
-        if sampled:
-            hs.set_profiling([dominant])
-        step()
-        if sampled:
-            hs.set_profiling(False)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, roofline, stage_us, info = measure(setup, args.steps, args.warmup, args.dirty,
+                                                args.submeshes, exchange, fence, overridden)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timers = hs.timers(reset=True)
-    info = hs.frame_info()
     if exchange is not None:
         regrown = exchange.regrown
-        exchange.finish()
+        try:
+            exchange.finish()
+        except ExchangeOverflow as exc:
+            print(f"bench.py: {exc}", file=sys.stderr)
+            return 3
         if exchange.regrown != regrown:
             print("bench.py: the exchange blocks overflowed inside the timed region", file=sys.stderr)
             return 3
@@ -272,28 +392,6 @@ def main() -> int:
     ms_per_step = elapsed * 1e3 / args.steps
     total_instances = n * world
     value = total_instances * args.steps / elapsed
-
-    dom_ms, dom_n = timers[dominant]
-    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
-    launches = 1 if dominant == "classify" else len(sc.level_offsets) - 1
-    survivors = sum(st.visible_count for st in info.views) + info.transparent_draw_count
-    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors, args.dirty == "local",
-                             args.submeshes)
-    achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-    overridden = (bool(args.instances) or args.dirty != "world" or args.submeshes != 1 or
-                  any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes")))
-    traffic, traffic_source = pmc_traffic(args.workload, overridden, KERNEL_NAMES[dominant],
-                                          {"fused": "true", "transform": "false"}.get(dominant))
-    roofline = {
-        "bound": "hbm", "kernel": KERNEL_NAMES[dominant],
-        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_source,
-        "avg_launch_us": round(dom_avg_s * 1e6 / launches, 2),
-        "launches_per_step": launches, "event_samples": dom_n,
-        "algorithmic_bytes_per_step": int(alg_bytes),
-    }
-    stage_us = {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in warm.items() if v[1]}
 
     result = {
         "metric": "instances/sec (transform+cull+sort)",
@@ -308,20 +406,50 @@ def main() -> int:
             "transparent_draws": info.transparent_draw_count,
             "moved_per_frame": "every node: " + ("TRS (locals rebuilt)" if args.dirty == "local"
                                                  else "world matrices re-propagated from cached locals"),
+            "timed_stages": "transform + multi-view cull + compaction + transparent key sort and draw "
+                            "emission, outputs left in HBM; the 144-byte candidate rows of "
+                            "application_build_world_payload are NOT in it (see dropin)",
             "exchange": ("one all-gather of packed blocks (visible lists + draw-key runs), "
                          "device-planned merge, overlapped with the next frame") if exchange is not None else "none",
         },
         "roofline": roofline,
+        "whole_frame_frac": round(roofline["algorithmic_bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+                                  / HBM_PEAK_GBS, 4),
         "stage_us_warmup": stage_us,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sc, planes, required, vs, args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(result), flush=True)  # out before any teardown
+    single = rank == 0 and world == 1
+    if single and not args.no_dropin and args.submeshes == 1 and exchange is None:
+        result["dropin"] = measure_dropin(setup, min(args.steps, 10), fence)
+    if single and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sc, setup.planes, setup.required, setup.vs, args.cpu_seconds)
     if world > 1:
         dist.barrier()  # no rank tears its communicator down while another still uses it
-    hs.close()
+    setup.close()
+    del setup, hs, sc
+
+    if single and not args.no_secondary and not overridden and exchange is None:
+        # the other single-GPU configurations, each with its own roofline (shorter runs)
+        secondary = []
+        for name in ("flat1m", "flat32m", "probes64", "deep16m"):
+            if name == args.workload:
+                continue
+            other = Setup(name, dict(WORKLOADS[name]), 0, local_rank, args.seed, 1)
+            steps = max(10, args.steps // 2)
+            el, roof, _, inf = measure(other, steps, max(3, args.warmup // 2), "world", 1, None, fence, False)
+            secondary.append({
+                "workload": f"{name}: {WORKLOADS[name]['desc']}", "instances_per_gpu": other.n,
+                "views": other.views, "steps": steps, "ms_per_step": el * 1e3 / steps,
+                "value": other.n * steps / el, "roofline": roof,
+                "whole_frame_frac": round(roof["algorithmic_bytes_per_step"] / (el / steps) / 1e9
+                                          / HBM_PEAK_GBS, 4),
+                "visible_camera": inf.views[0].visible_count,
+                "transparent_draws": inf.transparent_draw_count})
+            other.close()
+            del other
+        result["secondary"] = secondary
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -355,8 +483,10 @@ def cpu_baseline(sc, planes, required, vs, budget_s: float) -> dict:
             break
     o.baseline_destroy(h)
     out = {"value": sample * frames / dt, "unit": "instances/s", "cores": 1, "kind": "port",
-           "sample": f"{frames} frames of the first {sample} instances of the workload, "
-                     f"all {planes.shape[0]} views, {dt:.1f} s"}
+           "sample": f"{frames} frames of " + ("the first " if flat else "all ") +
+                     f"{sample} instances of the workload, all {planes.shape[0]} views, {dt:.1f} s; "
+                     "includes the 144-byte candidate emission of application_build_world_payload "
+                     "(the GPU figure beside it: dropin)"}
     if flat:
         out["all_cores"] = cpu_baseline_all_cores(o, sc, sample, local, planes, required, vs,
                                                   min(10.0, budget_s))

@@ -11,7 +11,7 @@ for rep in $(seq ${REPS:-3}); do
     cp "$ROOT/ab/libvkrhip_$which.so" "$ROOT/vulkan_renderer_amd/libvkrhip.so"
     for w in "$@"; do
       echo "## $which $w" >> "$OUT"
-      timeout -k 10 200 python3 "$ROOT/bench.py" --workload $w --no-cpu-baseline >> "$OUT" 2>&1
+      timeout -k 10 200 python3 "$ROOT/bench.py" --workload $w --no-cpu-baseline --no-secondary --no-dropin >> "$OUT" 2>&1
     done
   done
 done
@@ -23,5 +23,5 @@ for line in open(sys.argv[1]):
         tag = line[3:].strip()
     elif line.startswith("{"):
         d = json.loads(line); r = d["roofline"]
-        print(f'{tag:16s} {d["ms_per_step"]*1e3:9.1f} us/frame  fused {r["avg_launch_us"]*r["launches_per_step"]:8.1f} us')
+        print(f'{tag:16s} {d["ms_per_step"]*1e3:9.1f} us/frame  fused {r["avg_launch_us"]:8.1f} us')
 PY

@@ -9,7 +9,7 @@ for rep in 1 2; do
     cp "$ROOT/ab/libvkrhip_$which.so" "$ROOT/vulkan_renderer_amd/libvkrhip.so"
     for n in 1048576 4194304; do
       echo "## $which n=$n" >> "$OUT"
-      timeout -k 10 200 python3 "$ROOT/bench.py" --instances $n --exchange --no-cpu-baseline >> "$OUT" 2>&1
+      timeout -k 10 200 python3 "$ROOT/bench.py" --instances $n --exchange --no-cpu-baseline --no-secondary --no-dropin >> "$OUT" 2>&1
     done
   done
 done

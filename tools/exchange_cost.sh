@@ -7,7 +7,7 @@ OUT=$ROOT/$1
 for n in 1048576 4194304 16777216; do
   for x in "" "--exchange"; do
     echo "## n=$n $x" >> "$OUT"
-    timeout -k 10 200 python3 "$ROOT/bench.py" --instances $n $x --no-cpu-baseline >> "$OUT" 2>&1
+    timeout -k 10 200 python3 "$ROOT/bench.py" --instances $n $x --no-cpu-baseline --no-secondary --no-dropin >> "$OUT" 2>&1
   done
 done
 python3 - "$OUT" <<'PY'

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {
   name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$ROOT/$OUT/$name" --output-format csv -- \
-    python3 "$ROOT/bench.py" $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline \
+    python3 "$ROOT/bench.py" $BENCH_ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-dropin \
     > "$ROOT/$OUT/$name.log" 2>&1
 }
 BENCH_ARGS="$*"
