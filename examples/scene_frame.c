@@ -1,7 +1,7 @@
 /* A C host for the HIP scene path: what the reference's render thread would do
  * through include/vkr_hip_scene.h, with no Python and no C++ in between.
  *
- *   scene_frame <scene.bin> <result.bin>
+ *   scene_frame <scene.bin> <result.bin> [payload.bin]
  *
  * scene.bin  (little endian): uint64 nodes, levels, rows, views; then
  *            parent[nodes] u32, level_offsets[levels+1] u64, pos/quat/scale
@@ -11,6 +11,12 @@
  * result.bin: vkrhip_frame_info, world[nodes][16] f32, then per view its visible
  *            list (visible_count u32), then the sorted draw keys (u64) and the
  *            VkrDrawItem rows (48 B each).
+ * payload.bin (when named): the frame also produces the candidate rows and the
+ *            file takes what vkrhip_fill_world_payload hands back, i.e. the
+ *            reference's VkrWorldPassPayload: the 88-byte struct itself (its
+ *            pointers are meaningless in a file), the 12-byte VkrVisibilityStats,
+ *            then the arrays it points to: candidate rows (144 B), transmission
+ *            rows (144 B), draws (48 B), instances (80 B).
  * Exit code 0 on success; any library error is printed with its message. */
 #include <stdint.h>
 #include <stdio.h>
@@ -37,8 +43,8 @@ static void *read_array(FILE *f, size_t count, size_t size) {
   } while (0)
 
 int main(int argc, char **argv) {
-  if (argc != 3) {
-    fprintf(stderr, "usage: %s scene.bin result.bin\n", argv[0]);
+  if (argc != 3 && argc != 4) {
+    fprintf(stderr, "usage: %s scene.bin result.bin [payload.bin]\n", argv[0]);
     return 2;
   }
   FILE *in = fopen(argv[1], "rb");
@@ -81,7 +87,24 @@ int main(int argc, char **argv) {
   for (uint64_t i = 0; identity && i < rows; ++i) identity = node[i] == i;
   CHECK(ctx, vkrhip_set_candidates(ctx, rows, identity ? NULL : node, ident, matbits, bounds));
   CHECK(ctx, vkrhip_set_views(ctx, (uint32_t)views, planes, required, camera_view));
-  CHECK(ctx, vkrhip_frame(ctx, VKRHIP_STAGE_ALL));
+  CHECK(ctx, vkrhip_frame(ctx, VKRHIP_STAGE_ALL | (argc == 4 ? VKRHIP_STAGE_CANDIDATES : 0u)));
+  if (argc == 4) { /* what replaces application_build_world_payload (application.h:671-961) */
+    vkrhip_world_payload payload;
+    vkrhip_visibility_stats stats;
+    CHECK(ctx, vkrhip_fill_world_payload(ctx, &payload, &stats));
+    FILE *pf = fopen(argv[3], "wb");
+    if (!pf) {
+      perror(argv[3]);
+      return 2;
+    }
+    fwrite(&payload, sizeof payload, 1, pf);
+    fwrite(&stats, sizeof stats, 1, pf);
+    fwrite(payload.gpu_candidates, 144, payload.gpu_candidate_count, pf);
+    fwrite(payload.transmission_gpu_candidates, 144, payload.transmission_gpu_candidate_count, pf);
+    fwrite(payload.transparent_draws, 48, payload.transparent_draw_count, pf);
+    fwrite(payload.instances, 80, payload.instance_count, pf);
+    fclose(pf);
+  }
   vkrhip_frame_info info;
   CHECK(ctx, vkrhip_get_frame_info(ctx, &info));
 

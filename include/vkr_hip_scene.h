@@ -254,6 +254,39 @@ int vkrhip_frame(vkrhip_ctx *ctx, uint32_t stages);
 int vkrhip_get_frame_info(vkrhip_ctx *ctx, vkrhip_frame_info *out);
 int vkrhip_get_device_outputs(vkrhip_ctx *ctx, vkrhip_device_outputs *out);
 
+/* ---- the payload of the reference's world pass -------------------------------
+ * VkrWorldPassPayload (lib/src/renderer/vkr_render_packet.h:162-179, 88 bytes)
+ * and VkrVisibilityStats (lib/src/renderer/vkr_visibility.h:42-46) as
+ * application_build_world_payload leaves them (lib/src/application.h:946-960):
+ * vkrhip_fill_world_payload completes the last frame - which must have run
+ * VKRHIP_STAGE_CULL | VKRHIP_STAGE_TRANSPARENT | VKRHIP_STAGE_CANDIDATES - and
+ * fills both. The arrays the payload points to are host memory (pinned) owned by
+ * the context, valid until the next vkrhip_frame, like the reference's
+ * frame-scoped scratch allocations (vkr_render_packet.h:121-125). The frame's
+ * counts reach the host through a pinned block the device writes, not through
+ * copies of their own.
+ * More source rows than VKRHIP_DRAW_CANDIDATE_CAPACITY is not a failure, as in
+ * the reference (application.h:703-711): the payload is empty except for
+ * gpu_candidate_count = capacity + 1, objects_tested likewise, and packet
+ * validation rejects the frame. stats may be NULL. */
+#define VKRHIP_DRAW_CANDIDATE_CAPACITY 262144u /* VKR_GPU_DRAW_CANDIDATE_CAPACITY, vkr_gpu_abi.h:9 */
+typedef struct vkrhip_world_payload {
+  const void *gpu_candidates; /* gpu_candidate_count x VkrWorldDrawCandidate (144 B) */
+  uint32_t gpu_candidate_count;
+  uint32_t gpu_camera_opaque_candidate_count;
+  uint32_t gpu_shadow_candidate_count;
+  const void *transmission_gpu_candidates;
+  uint32_t transmission_gpu_candidate_count;
+  const void *transparent_draws; /* transparent_draw_count x VkrDrawItem (48 B) */
+  uint32_t transparent_draw_count;
+  const void *instances; /* instance_count x VkrInstanceDataGPU (80 B) */
+  uint32_t instance_count;
+  const void *text_draws; /* not produced by this path: NULL, 0 */
+  uint32_t text_draw_count;
+} vkrhip_world_payload;
+int vkrhip_fill_world_payload(vkrhip_ctx *ctx, vkrhip_world_payload *out_payload,
+                              vkrhip_visibility_stats *out_stats);
+
 /* Synchronous device-to-host copies of outputs (after the frame completes). */
 int vkrhip_read_world(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out16);
 int vkrhip_read_locals(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out16);
@@ -420,6 +453,23 @@ int vkrhip_exchange_configure(vkrhip_ctx *ctx, uint32_t world, uint32_t vis_cap,
 int vkrhip_exchange_run(vkrhip_ctx *ctx);
 int vkrhip_exchange_finish(vkrhip_ctx *ctx, uint64_t *result_out,
                            const uint32_t **merged_visible_dev, const uint64_t **merged_keys_dev);
+
+/* ---- sharding a hierarchy over GPUs (no reference counterpart: the reference
+ * runs on one GPU) -----------------------------------------------------------
+ * Cuts a hierarchy in BFS order (the order vkrhip_levelize produces: parents
+ * ascend with their children, every parent one level up) into `shards` pieces
+ * that need no communication to propagate transforms: levels [0,
+ * replicated_levels) - a handful of nodes - go to every shard whole; the nodes of
+ * level `replicated_levels` are dealt out in contiguous runs of about equal
+ * subtree weight, and every deeper level follows its parents, so a shard owns
+ * whole subtrees. out_ranges[(s * levels + l) * 2 + {0, 1}] = [begin, end) of
+ * level l on shard s, in the numbering of the input. A shard's scene is the
+ * concatenation of its ranges level by level (parents renumbered accordingly);
+ * which shard draws the rows of a replicated node is the caller's choice.
+ * Returns VKRHIP_ERR_STATE when the numbering is not of that shape. Host side. */
+int vkrhip_shard_hierarchy(const uint32_t *parent, uint64_t n, const uint64_t *level_offsets,
+                           uint32_t levels, uint32_t shards, uint32_t replicated_levels,
+                           uint64_t *out_ranges);
 
 /* ---- the exchange merge without an allocation -------------------------------
  * No counterpart in the reference. For callers that cannot allocate device

@@ -521,6 +521,7 @@ class Reference:
             raise FileNotFoundError(path)
         self.lib = L = C.CDLL(path)
         L.ref_layout.argtypes = [u32p]
+        L.ref_payload_layout.argtypes = [u32p]
         L.ref_mat4_mul.argtypes = [f32p, f32p, f32p]
         L.ref_mat4_mul_vec3.argtypes = [f32p, f32p, f32p]
         L.ref_mat4_mul_vec4.argtypes = [f32p, f32p, f32p]
@@ -560,6 +561,14 @@ class Reference:
     def layout(self):
         out = np.zeros(32, np.uint32)
         self.lib.ref_layout(out)
+        return out
+
+    def payload_layout(self):
+        """sizeof/offsetof of VkrWorldPassPayload and VkrVisibilityStats as the
+        reference's header (application.h:696-750) compiles here, then
+        VKR_GPU_DRAW_CANDIDATE_CAPACITY."""
+        out = np.zeros(18, np.uint32)
+        self.lib.ref_payload_layout(out)
         return out
 
     def mat4_mul(self, a, b):

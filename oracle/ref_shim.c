@@ -52,6 +52,30 @@ static VkrFrustum load_frustum(const float *planes24) {
 }
 
 /* ---- struct layout probes ------------------------------------------------ */
+/* VkrWorldPassPayload (vkr_render_packet.h:162-179) and VkrVisibilityStats
+ * (vkr_visibility.h:42-46): what vkrhip_fill_world_payload writes. */
+void ref_payload_layout(uint32_t *out) {
+  uint32_t i = 0;
+  out[i++] = sizeof(VkrWorldPassPayload);
+  out[i++] = offsetof(VkrWorldPassPayload, gpu_candidates);
+  out[i++] = offsetof(VkrWorldPassPayload, gpu_candidate_count);
+  out[i++] = offsetof(VkrWorldPassPayload, gpu_camera_opaque_candidate_count);
+  out[i++] = offsetof(VkrWorldPassPayload, gpu_shadow_candidate_count);
+  out[i++] = offsetof(VkrWorldPassPayload, transmission_gpu_candidates);
+  out[i++] = offsetof(VkrWorldPassPayload, transmission_gpu_candidate_count);
+  out[i++] = offsetof(VkrWorldPassPayload, transparent_draws);
+  out[i++] = offsetof(VkrWorldPassPayload, transparent_draw_count);
+  out[i++] = offsetof(VkrWorldPassPayload, instances);
+  out[i++] = offsetof(VkrWorldPassPayload, instance_count);
+  out[i++] = offsetof(VkrWorldPassPayload, text_draws);
+  out[i++] = offsetof(VkrWorldPassPayload, text_draw_count);
+  out[i++] = sizeof(VkrVisibilityStats);
+  out[i++] = offsetof(VkrVisibilityStats, objects_tested);
+  out[i++] = offsetof(VkrVisibilityStats, objects_culled_camera);
+  out[i++] = offsetof(VkrVisibilityStats, objects_without_bounds);
+  out[i++] = VKR_GPU_DRAW_CANDIDATE_CAPACITY;
+}
+
 void ref_layout(uint32_t *out) {
   uint32_t i = 0;
   out[i++] = sizeof(Mat4);

@@ -4,6 +4,8 @@ Runs only where the reference checkout was available to build oracle/_ref;
 elsewhere the committed golden vectors (test_oracle_golden.py) carry the same
 evidence.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -145,6 +147,30 @@ def test_layout(reference):
     lay = reference.layout()
     assert list(lay[:28]) == [64, 16, 144, 8, 16, 20, 32, 112, 128, 132, 48, 20, 28, 32, 40, 80, 64,
                               112, 96, 80, 48, 32, 192, 262144, 65536, 1, 2, 4]
+
+
+def test_payload_layout(reference):
+    """vkrhip_world_payload / vkrhip_visibility_stats are byte for byte the reference's
+    VkrWorldPassPayload / VkrVisibilityStats (application.h:696-750) as its own header
+    compiles on this box, and the candidate capacity behind the CAP+1 convention is
+    the reference's VKR_GPU_DRAW_CANDIDATE_CAPACITY."""
+    import ctypes as C
+    from vulkan_renderer_amd import _native as N
+    lay = [int(x) for x in reference.payload_layout()]
+    P, S = N.WorldPayload, N.VisibilityStats
+    fields = ("gpu_candidates", "gpu_candidate_count", "gpu_camera_opaque_candidate_count",
+              "gpu_shadow_candidate_count", "transmission_gpu_candidates",
+              "transmission_gpu_candidate_count", "transparent_draws", "transparent_draw_count",
+              "instances", "instance_count", "text_draws", "text_draw_count")
+    assert lay[0] == C.sizeof(P) == 88
+    assert lay[1:13] == [getattr(P, f).offset for f in fields]
+    assert lay[13] == C.sizeof(S) == 12
+    assert lay[14:17] == [S.objects_tested.offset, S.objects_culled_camera.offset,
+                          S.objects_without_bounds.offset]
+    assert lay[17] == 262144
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                               "include", "vkr_hip_scene.h")).read()
+    assert "#define VKRHIP_DRAW_CANDIDATE_CAPACITY 262144u" in header
 
 
 def test_propagation(oracle, reference):

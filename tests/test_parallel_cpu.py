@@ -132,3 +132,76 @@ def test_two_rank_exchange_equals_single_process(oracle, tmp_path):
         assert count > 20
         off = int(r0["view_offsets"][v])
         assert (r0["vis"][off: off + count] == whole["visible"][v, :count]).all(), f"view {v} list"
+
+
+def test_sharded_hierarchy_union_equals_the_whole_scene(oracle):
+    """A depth-8 hierarchy cut into whole subtrees (vkrhip_shard_hierarchy, top level
+    replicated): every shard's oracle frame, put together, is the frame of the
+    whole scene - world matrices of every node, per-view visible sets and the
+    merged draw order. Rows are numbered shard after shard (the rows of the
+    replicated nodes belong to shard 0), which is the row order of the whole scene."""
+    from helpers import oracle_frame, view_set
+    from vulkan_renderer_amd import synth
+    from vulkan_renderer_amd.scene import shard_hierarchy, shard_local_hierarchy
+    sc = synth.deep_scene(60000, depth=8, seed=5, fanout=4, roots=6, blend_fraction=0.2)
+    vs = synth.camera_views(cascades=2, eye=(0.0, 0.0, 400.0), target=(0.0, 0.0, 0.0), far=1500.0,
+                            fov_deg=50.0)
+    planes, required = view_set(vs)
+    views = planes.shape[0]
+    shards = 3
+    ranges = shard_hierarchy(sc.parent, sc.level_offsets, shards, replicated_levels=1)
+    levels = sc.level_offsets.shape[0] - 1
+    # the ranges tile every level below the replicated one, in order
+    for l in range(1, levels):
+        assert int(ranges[0, l, 0]) == int(sc.level_offsets[l])
+        assert int(ranges[-1, l, 1]) == int(sc.level_offsets[l + 1])
+        assert (ranges[1:, l, 0] == ranges[:-1, l, 1]).all()
+    sizes = (ranges[:, :, 1] - ranges[:, :, 0]).sum(axis=1).astype(np.int64)
+    assert sizes.max() < 1.3 * sizes.min(), "about equal shards"
+
+    world_whole = np.zeros((sc.n, 16), np.float32)
+    frames, row_node, bases = [], [], []
+    base = 0
+    for s in range(shards):
+        nodes, local_parent, offsets = shard_local_hierarchy(sc.parent, ranges[s])
+        # rows: shard 0 draws every node it holds, the others only what they own
+        owned = np.ones(nodes.shape[0], bool) if s == 0 else nodes >= sc.level_offsets[1]
+        rows = np.flatnonzero(owned).astype(np.uint32)
+        local = synth.Scene(local_parent, offsets, sc.pos[nodes], sc.quat[nodes], sc.scale[nodes],
+                            sc.ident[nodes[rows]], sc.matbits[nodes[rows]], sc.bounds[nodes[rows]],
+                            node=rows)
+        f = oracle_frame(oracle, local, planes, required, vs.view, vs.projection, index_base=base)
+        world_whole[nodes] = f["world"]
+        frames.append(f)
+        row_node.append(nodes[rows])
+        bases.append(base)
+        base += rows.shape[0]
+    row_node = np.concatenate(row_node)
+    assert row_node.shape[0] == sc.n and np.unique(row_node).shape[0] == sc.n
+
+    whole = synth.Scene(sc.parent, sc.level_offsets, sc.pos, sc.quat, sc.scale, sc.ident[row_node],
+                        sc.matbits[row_node], sc.bounds[row_node], node=row_node.astype(np.uint32))
+    ref = oracle_frame(oracle, whole, planes, required, vs.view, vs.projection)
+    assert world_whole.view(np.uint32).tobytes() == ref["world"].view(np.uint32).tobytes()
+    # visible lists: per (view, bucket) the shards' ranges one after another
+    for v in range(views):
+        st = ref["states"][v]
+        for b in range(4):
+            off, cnt = (int(x) for x in st["execution_ranges"][b])
+            parts = []
+            for f in frames:
+                o, c = (int(x) for x in f["states"][v]["execution_ranges"][b])
+                parts.append(f["visible"][v, o: o + c])
+            assert (np.concatenate(parts) == ref["visible"][v, off: off + cnt]).all(), (v, b)
+    # draw order: the merge of the shards' descending key runs
+    merged = oracle.merge_runs_desc([f["payload"]["sort_keys"] for f in frames])
+    assert merged.shape[0] > 100 and (merged == ref["payload"]["sort_keys"]).all()
+
+
+def test_shard_hierarchy_refuses_other_numberings():
+    from vulkan_renderer_amd import _native as N
+    from vulkan_renderer_amd.scene import shard_hierarchy
+    parent = np.array([0xFFFFFFFF, 0xFFFFFFFF, 1, 0, 1], np.uint32)   # parents do not ascend
+    with pytest.raises(N.VkrHipError) as e:
+        shard_hierarchy(parent, np.array([0, 2, 5], np.uint64), 2)
+    assert e.value.code == N.ERR_STATE

@@ -8,8 +8,9 @@ from . import _native  # noqa: F401
 from .scene import (CANDIDATE_DT, DRAW_DT, INSTANCE_DT, FrameResult, HipScene, ViewState,  # noqa: F401
                     build_view_set, frustum_from_matrix, frustum_from_view_projection, levelize,
                     effective_visibility,
-                    mat4_mul)
+                    mat4_mul, shard_hierarchy, shard_local_hierarchy, shard_nodes)
 
 __all__ = ["HipScene", "FrameResult", "ViewState", "build_view_set", "frustum_from_matrix",
-           "frustum_from_view_projection", "levelize", "effective_visibility", "mat4_mul", "DRAW_DT", "INSTANCE_DT",
+           "frustum_from_view_projection", "levelize", "effective_visibility", "mat4_mul", "shard_hierarchy",
+           "shard_local_hierarchy", "shard_nodes", "DRAW_DT", "INSTANCE_DT",
            "CANDIDATE_DT"]

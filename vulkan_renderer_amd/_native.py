@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize", "vkrhip_effective_visibility",
     "vkrhip_static_init", "vkrhip_exchange_merge_static",
+    "vkrhip_fill_world_payload", "vkrhip_shard_hierarchy",
 ]
 
 
@@ -100,6 +101,24 @@ class FrameInfo(C.Structure):
         ("invalid_submesh_count", C.c_uint32),
         ("near_plane_ties", C.c_uint64 * MAX_VIEWS),
         ("views", CompactionState * MAX_VIEWS),
+    ]
+
+
+class WorldPayload(C.Structure):
+    """vkrhip_world_payload = VkrWorldPassPayload (lib/src/renderer/vkr_render_packet.h:162-179)."""
+    _fields_ = [
+        ("gpu_candidates", C.c_void_p),
+        ("gpu_candidate_count", C.c_uint32),
+        ("gpu_camera_opaque_candidate_count", C.c_uint32),
+        ("gpu_shadow_candidate_count", C.c_uint32),
+        ("transmission_gpu_candidates", C.c_void_p),
+        ("transmission_gpu_candidate_count", C.c_uint32),
+        ("transparent_draws", C.c_void_p),
+        ("transparent_draw_count", C.c_uint32),
+        ("instances", C.c_void_p),
+        ("instance_count", C.c_uint32),
+        ("text_draws", C.c_void_p),
+        ("text_draw_count", C.c_uint32),
     ]
 
 
@@ -198,6 +217,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_exchange_result_words.restype = u64
     L.vkrhip_exchange_pack.argtypes = [vp, vp, u32, u32]
     L.vkrhip_exchange_merge.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.vkrhip_fill_world_payload.argtypes = [vp, C.POINTER(WorldPayload), C.POINTER(VisibilityStats)]
+    L.vkrhip_shard_hierarchy.argtypes = [vp, u64, vp, u32, u32, u32, vp]
     L.vkrhip_static_init.argtypes = [C.c_int]
     L.vkrhip_exchange_merge_static.argtypes = [C.c_int, u32, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vkrhip_frustum_from_matrix.argtypes = [vp, vp]

@@ -68,6 +68,24 @@ constexpr uint32_t STAT_SHARDS = 64;
 constexpr uint32_t TIE_SHARDS = 16;
 __device__ __forceinline__ uint32_t stat_shard() { return (blockIdx.x % STAT_SHARDS) * CNT_COUNT; }
 
+// The frame's counters, summed over their shards, to pinned host memory: word 0
+// takes the frame serial last, so a host that sees the serial sees the totals.
+__global__ __launch_bounds__(64) void k_publish_counts(const uint32_t *counters, uint32_t *host_block,
+                                                       uint32_t serial) {
+  const uint32_t t = threadIdx.x;
+  if (t < (uint32_t)CNT_COUNT) {
+    uint32_t sum = 0u;
+    for (uint32_t sh = 0; sh < STAT_SHARDS; ++sh) sum += counters[sh * CNT_COUNT + t];
+    host_block[1u + t] = sum;
+  }
+  __threadfence_system();
+  __builtin_amdgcn_wave_barrier();
+  if (t == 0) {
+    __threadfence_system();
+    *reinterpret_cast<volatile uint32_t *>(host_block) = serial;
+  }
+}
+
 struct CompactionState {  // VkrGpuDrawCompactionState, vkr_gpu_abi.h:95-103
   uint32_t execution_ranges[4][2];
   uint32_t bucket_counts[4];

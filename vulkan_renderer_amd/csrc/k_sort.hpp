@@ -13,8 +13,9 @@
 // ascending sort on key bits [32, 64) followed by reading the result backwards
 // yields descending keys with larger source index first among equal depths -
 // exactly descending order on the full 64-bit key - while only the 32 depth
-// bits have to be moved through the radix passes. Per 8-bit pass: per-tile
-// digit histogram -> per-digit exclusive scan over the tiles -> stable scatter.
+// bits have to be moved through the radix passes: one histogram launch for all
+// four digit positions, then one launch per 8-bit pass (decoupled look-back
+// between the tiles of a pass, see k_sort_pass).
 // All kernels read the count on the device (no host round trip between cull
 // and sort). Ranking inside a wave is a
 // 64-wide match on the digit built from eight ballots, with per-wave running
@@ -86,15 +87,6 @@ __device__ __forceinline__ void wave_rank(const uint64_t (&key)[STEPS], const bo
     if ((uint32_t)k < steps) rank[k] += (uint32_t)__shfl((int)before[k], (int)leader[k], 64);
 }
 
-struct SortArgs {
-  const uint64_t *keys_in;
-  uint64_t *keys_out;
-  uint32_t *hist;            // [digit][tiles_stride]
-  uint32_t *totals;          // [SORT_RADIX] keys per digit (this pass)
-  const uint32_t *counters;  // CNT_TRANSPARENT
-  uint32_t tiles_stride;
-  uint32_t shift;
-};
 
 // LDS of the single-workgroup sort (the keys stay in global memory).
 struct SmallSortShared {
@@ -209,76 +201,108 @@ __device__ __forceinline__ bool block_radix_pass(const uint64_t *src, uint64_t *
   return true;
 }
 
-__global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(SortArgs a) {
-  __shared__ uint32_t s_hist[SORT_RADIX];
+// ---------------------------------------------------------------------------
+// Large counts: four stable 8-bit passes, ONE launch each, behind one histogram
+// launch that reads the keys once for all four digit positions.
+//
+// A pass must know, for every (tile, digit), how many keys with that digit lie
+// in the tiles before it. Instead of a histogram and a scan launch per pass, a
+// block publishes its tile's digit counts as soon as it has ranked the tile and
+// then looks back over the tiles before it until it meets one whose running
+// total is known ("decoupled look-back"). Tiles are handed out by a ticket
+// counter, so a block only ever waits for tiles taken earlier, i.e. for blocks
+// that are already running: every wait ends. A status word is
+//   frame serial << 32 | state << 30 | count      (state 1: the tile's own count,
+//                                                  state 2: running total up to and
+//                                                  including the tile)
+// and needs no clearing between frames (a stale serial reads as "not there yet").
+// The global digit histograms, the ticket counters and the stall flag live in
+// the frame's zeroed counter block.
+// ---------------------------------------------------------------------------
+constexpr int SORT_PASSES = 4;
+constexpr uint32_t SORT_STATE_WORDS = SORT_PASSES * SORT_RADIX + SORT_PASSES + 4;  // see SortState
+constexpr uint32_t SORT_SPIN_LIMIT = 1u << 24;  // look-back polls before a block gives up
+
+struct SortState {  // zero at the start of a frame
+  uint32_t hist[SORT_PASSES][SORT_RADIX];  // keys per digit, per pass
+  uint32_t ticket[SORT_PASSES];            // next tile of the pass
+  uint32_t stalled;                        // a look-back gave up (never expected)
+  uint32_t reserved[3];
+};
+static_assert(sizeof(SortState) == SORT_STATE_WORDS * sizeof(uint32_t), "SortState layout");
+
+struct SortArgs {
+  const uint64_t *keys_in;
+  uint64_t *keys_out;
+  SortState *state;
+  unsigned long long *status;  // [SORT_PASSES][tiles_stride][SORT_RADIX]
+  const uint32_t *counters;    // CNT_TRANSPARENT
+  uint32_t tiles_stride;
+  uint32_t pass;               // 0..3: key bits [32 + 8 pass, 40 + 8 pass)
+  uint32_t serial;             // frame serial of the status words (never 0)
+};
+
+// Digit histograms of all four passes in one read of the keys.
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_hist(SortArgs a) {
+  __shared__ uint32_t s_hist[SORT_PASSES][SORT_RADIX];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
+  if (blockIdx.x >= tiles) return;  // block-uniform
+#pragma unroll
+  for (int p = 0; p < SORT_PASSES; ++p) s_hist[p][t] = 0u;
+  __syncthreads();
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    s_hist[t] = 0u;
-    __syncthreads();
     const uint32_t base = tile * SORT_TILE;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
       const uint32_t idx = base + (uint32_t)k * SORT_BLOCK + t;
-      if (idx < count) atomicAdd(&s_hist[(uint32_t)(a.keys_in[idx] >> a.shift) & 0xffu], 1u);
+      if (idx < count) {
+        const uint32_t hi = (uint32_t)(a.keys_in[idx] >> 32);
+#pragma unroll
+        for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&s_hist[p][(hi >> (8 * p)) & 0xffu], 1u);
+      }
     }
-    __syncthreads();
-    a.hist[t * a.tiles_stride + tile] = s_hist[t];
-    __syncthreads();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < SORT_PASSES; ++p) {
+    const uint32_t c = s_hist[p][t];
+    if (c) atomicAdd(&a.state->hist[p][t], c);
   }
 }
 
-// Exclusive scan of every digit's tile row, one block per digit: thread t owns a
-// run of consecutive tiles, sums it, a block-wide scan of the 256 sums gives its
-// start, and a second sweep writes the row-local exclusive prefix in place. The
-// digit's total goes to totals[digit]; the scatter kernel adds the totals of the
-// smaller digits.
-__global__ __launch_bounds__(SORT_BLOCK) void k_radix_scan(SortArgs a) {
-  __shared__ uint32_t s_wave[SORT_BLOCK / 64];
-  const uint32_t count = a.counters[CNT_TRANSPARENT];
-  const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
-  const uint32_t digit = blockIdx.x;
-  const uint32_t chunk = (tiles + SORT_BLOCK - 1) / SORT_BLOCK;
-  const uint32_t begin = min(threadIdx.x * chunk, tiles);
-  const uint32_t end = min(begin + chunk, tiles);
-  uint32_t *row = a.hist + (uint64_t)digit * a.tiles_stride;
-  uint32_t sum = 0u;
-#pragma unroll 4
-  for (uint32_t k = begin; k < end; ++k) sum += row[k];
-  uint32_t total;
-  uint32_t run = block_exclusive_scan(sum, s_wave, &total);
-#pragma unroll 4
-  for (uint32_t k = begin; k < end; ++k) {
-    const uint32_t c = row[k];
-    row[k] = run;
-    run += c;
-  }
-  if (threadIdx.x == 0) a.totals[digit] = total;
+__device__ __forceinline__ unsigned long long sort_status(uint32_t serial, uint32_t state,
+                                                          uint32_t count) {
+  return ((unsigned long long)serial << 32) | ((unsigned long long)state << 30) | count;
 }
 
-// Stable scatter. Wave w of the block owns keys [w*512, w*512+512) of the tile
+// One stable pass. Wave w of the block owns keys [w*512, w*512+512) of its tile
 // and walks them in 8 steps of 64 consecutive keys, so (wave, step, lane) order
 // is memory order.
-__global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
   __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave digit counts, then bases
-  __shared__ uint32_t s_base[SORT_RADIX];      // global base of (digit, tile)
   __shared__ uint32_t s_wave[SORT_BLOCK / 64];
+  __shared__ uint32_t s_tile;
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
   const uint32_t wave = t >> 6;
   const uint32_t lane = t & 63u;
-  if (blockIdx.x >= tiles) return;  // block-uniform
+  const uint32_t shift = 32u + 8u * a.pass;
+  if (blockIdx.x >= tiles) return;  // block-uniform: the grid covers the capacity
   // keys with smaller digits come first: exclusive scan of the digit totals
   uint32_t all_keys;
-  const uint32_t digit_base = block_exclusive_scan(a.totals[t], s_wave, &all_keys);
+  const uint32_t digit_base = block_exclusive_scan(a.state->hist[a.pass][t], s_wave, &all_keys);
+  unsigned long long *status = a.status + (size_t)a.pass * a.tiles_stride * SORT_RADIX;
 
-  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    __syncthreads();  // previous tile's readers are done
+  for (;;) {
+    __syncthreads();  // the previous tile's readers are done with the tables
+    if (t == 0) s_tile = atomicAdd(&a.state->ticket[a.pass], 1u);
     for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
-    s_base[t] = digit_base + a.hist[t * a.tiles_stride + tile];
     __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= tiles) break;  // block-uniform
 
     uint64_t key[SORT_ITEMS];
     bool valid[SORT_ITEMS];
@@ -290,24 +314,83 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(SortArgs a) {
       valid[k] = idx < count;
       key[k] = valid[k] ? a.keys_in[idx] : 0ull;
     }
-    wave_rank<SORT_ITEMS>(key, valid, SORT_ITEMS, a.shift, s_whist[wave], rank);
+    wave_rank<SORT_ITEMS>(key, valid, SORT_ITEMS, shift, s_whist[wave], rank);
     __syncthreads();
-    // exclusive prefix of the per-wave digit totals across waves, plus the
-    // global base of this tile's digit run
+    // thread t = digit t: the tile's count, published at once for the tiles behind
+    uint32_t c[4], mine = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      c[w] = s_whist[w][t];
+      mine += c[w];
+    }
+    unsigned long long *own = status + (size_t)tile * SORT_RADIX + t;
+    __hip_atomic_store(own, sort_status(a.serial, tile == 0u ? 2u : 1u, mine), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    // look back: keys of this digit in the tiles before this one
+    uint32_t before = 0u;
+    if (tile != 0u) {
+      // eight tiles per step, nearest first: their status words are independent loads,
+      // so a step costs one memory round trip, not eight
+      constexpr uint32_t LOOK = 8;
+      uint32_t polls = 0u;
+      bool done = false;
+      for (uint32_t hi = tile; hi != 0u && !done;) {
+        const uint32_t n = min(hi, LOOK);
+        for (;;) {
+          unsigned long long v[LOOK];
+#pragma unroll
+          for (uint32_t j = 0; j < LOOK; ++j) {
+            const uint32_t p = hi - 1u - min(j, n - 1u);  // (slots past n repeat the last tile)
+            v[j] = __hip_atomic_load(status + (size_t)p * SORT_RADIX + t, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+          }
+          // nearest first: add counts until a running total (nothing further back is
+          // needed, and it may not be there yet) or a tile that has not published
+          uint32_t sum = 0u;
+          bool blocked = false, total = false;
+#pragma unroll
+          for (uint32_t j = 0; j < LOOK; ++j) {
+            if (j < n && !blocked && !total) {
+              const uint32_t state = (uint32_t)(v[j] >> 30) & 3u;
+              if ((uint32_t)(v[j] >> 32) != a.serial || state == 0u) {
+                blocked = true;
+              } else {
+                sum += (uint32_t)v[j] & 0x3fffffffu;
+                total = state == 2u;
+              }
+            }
+          }
+          if (!blocked) {
+            before += sum;
+            done = total;
+            break;
+          }
+          if (++polls > SORT_SPIN_LIMIT) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (polls > SORT_SPIN_LIMIT) {  // never expected: leave a mark and get out
+          a.state->stalled = 1u;
+          break;
+        }
+        hi -= n;
+      }
+      __hip_atomic_store(own, sort_status(a.serial, 2u, before + mine), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // exclusive prefix of the per-wave counts, behind the digit's global base
     {
-      uint32_t run = s_base[t];
+      uint32_t run = digit_base + before;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const uint32_t c = s_whist[w][t];
         s_whist[w][t] = run;
-        run += c;
+        run += c[w];
       }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
       if (valid[k]) {
-        const uint32_t digit = (uint32_t)(key[k] >> a.shift) & 0xffu;
+        const uint32_t digit = (uint32_t)(key[k] >> shift) & 0xffu;
         a.keys_out[s_whist[wave][digit] + rank[k]] = key[k];
       }
     }
@@ -505,21 +588,22 @@ struct CandidateEmitArgs {
 };
 
 // application_emit_world_source, application.h:617-641: one 144-byte
-// VkrWorldDrawCandidate per source row, written as nine 16-byte pieces by nine
-// of every sixteen lanes.
+// VkrWorldDrawCandidate per source row, written as nine 16-byte pieces. Thread g
+// writes piece g of the output array as a whole (row g / 9, piece g % 9), so every
+// lane is busy and every wave store covers 1 KiB of consecutive bytes.
 __global__ __launch_bounds__(256) void k_emit_candidates(CandidateEmitArgs a) {
-  const uint64_t out_row = (uint64_t)blockIdx.x * 16u + (threadIdx.x >> 4);
-  const uint32_t piece = threadIdx.x & 15u;
-  if (out_row >= a.n || piece >= 9u) return;
+  const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint64_t out_row = g / 9u;
+  const uint32_t piece = (uint32_t)(g - out_row * 9u);
+  if (out_row >= a.n) return;
   // the transmission stream repeats the rows of the transmissive sources
   // (application.h:643-645)
   const uint64_t row = a.list ? a.list[out_row] : out_row;
-  const uint4 id0 = a.ident[row * 2u];
-  const uint4 id1 = a.ident[row * 2u + 1u];
-  uint4 o;
+  uint4 o;  // (each piece loads only what it is made of)
   if (piece == 0u) {
-    o = id0;  // mesh, geometry
+    o = a.ident[row * 2u];  // mesh, geometry
   } else if (piece == 1u) {
+    const uint4 id1 = a.ident[row * 2u + 1u];
     o = make_uint4(id1.x, id1.y, id1.z, 0u);  // submesh_index, material, pad
   } else if (piece < 6u) {
     const uint64_t nd = a.node ? a.node[row] : row;
@@ -527,7 +611,8 @@ __global__ __launch_bounds__(256) void k_emit_candidates(CandidateEmitArgs a) {
     o = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z),
                    __float_as_uint(c.w));
   } else if (piece == 6u) {
-    o = make_uint4(encode_scene_object_id(id1.w), 0u, 0u, 0u);
+    const uint32_t render_id = reinterpret_cast<const uint32_t *>(a.ident)[row * 8u + 7u];
+    o = make_uint4(encode_scene_object_id(render_id), 0u, 0u, 0u);
   } else if (piece == 7u) {
     const float4 s = a.sphere[row];
     o = make_uint4(__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.z),

@@ -131,7 +131,11 @@ struct vkrhip_ctx {
   bool block_clean[2] = {true, true};
   static constexpr size_t kCountersBytes = sizeof(uint32_t) * CNT_COUNT * STAT_SHARDS;
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
-  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes;
+  static constexpr size_t kSortStateBytes = sizeof(SortState);
+  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes + kSortStateBytes;
+  SortState *sort_state() const {
+    return reinterpret_cast<SortState *>(counter_block(cur_block) + kCountersBytes + kTiesBytes);
+  }
   uint8_t *counter_block(uint32_t i) const { return frame_zero.p + (size_t)i * kBlockBytes; }
   uint32_t *counters() const { return reinterpret_cast<uint32_t *>(counter_block(cur_block)); }
   unsigned long long *ties() const {
@@ -165,13 +169,21 @@ struct vkrhip_ctx {
   // transparent
   DevBuf<uint64_t> keys_a, keys_b, out_keys;
   DevBuf<uint32_t> out_source;
-  DevBuf<uint32_t> hist;
+  DevBuf<unsigned long long> sort_status;  // look-back words of the radix passes
   uint32_t sort_tiles_stride = 0;
+  uint32_t sort_serial = 0;  // tags the status words of one sort (never 0)
   DevBuf<uint4> draws;
   DevBuf<float4> instances;
 
   // pinned host word the scan kernel writes (transparent count + 1; 0 = unknown)
   uint32_t *host_hint = nullptr;
+  // pinned host block the frame's counters are published to when the candidate rows
+  // are produced (word 0: frame serial, written last; then CNT_COUNT totals), and the
+  // pinned arrays vkrhip_fill_world_payload hands out
+  uint32_t *host_counts = nullptr;
+  uint32_t publish_serial = 0;
+  void *pay_candidates = nullptr, *pay_transmission = nullptr, *pay_draws = nullptr, *pay_instances = nullptr;
+  size_t pay_candidates_bytes = 0, pay_transmission_bytes = 0, pay_draws_bytes = 0, pay_instances_bytes = 0;
 
   // merge scratch
   DevBuf<const uint64_t *> merge_ptrs;
@@ -595,6 +607,8 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
     HIP_TRY(c, hipHostMalloc((void **)&c->host_hint, 64, hipHostMallocMapped));
     c->host_hint[0] = 0u;
+    HIP_TRY(c, hipHostMalloc((void **)&c->host_counts, 256, hipHostMallocMapped));
+    std::memset(c->host_counts, 0, 256);
     c->visible_stride = c->cfg.visible_capacity;
     TRY(dev_alloc(c, c->visible, (size_t)c->cfg.max_views * c->visible_stride));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -670,7 +684,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->keys_b);
   dev_free(c->out_keys);
   dev_free(c->out_source);
-  dev_free(c->hist);
+  dev_free(c->sort_status);
   dev_free(c->draws);
   dev_free(c->instances);
   dev_free(c->merge_ptrs);
@@ -695,6 +709,9 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->exch_prefix);
   dev_free(c->exch_runs);
   if (c->host_hint) (void)hipHostFree(c->host_hint);
+  if (c->host_counts) (void)hipHostFree(c->host_counts);
+  for (void *p : {c->pay_candidates, c->pay_transmission, c->pay_draws, c->pay_instances})
+    if (p) (void)hipHostFree(p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -939,8 +956,15 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
     TRY(dev_alloc(c, c->keys_b, tcap));
     TRY(dev_alloc(c, c->out_keys, tcap));
     TRY(dev_alloc(c, c->out_source, tcap));
+    if (tcap >= (1ull << 30))
+      return fail(c, VKRHIP_ERR_CAPACITY, "more than 2^30 sortable blend rows on one GPU");
     c->sort_tiles_stride = (uint32_t)ceil_div(tcap, SORT_TILE);
-    TRY(dev_alloc(c, c->hist, (size_t)SORT_RADIX * c->sort_tiles_stride + SORT_RADIX));
+    // (zeroed once: a status word of another sort must never look like one of ours)
+    const size_t status_words = (size_t)SORT_PASSES * c->sort_tiles_stride * SORT_RADIX;
+    TRY(dev_alloc(c, c->sort_status, status_words));
+    HIP_TRY(c, hipMemsetAsync(c->sort_status.p, 0, c->sort_status.count * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sort_serial = 0;
     TRY(dev_alloc(c, c->draws, tcap * 3));
     TRY(dev_alloc(c, c->instances, tcap * 5));
     c->tcap = tcap;
@@ -1430,20 +1454,23 @@ static int launch_transparent(vkrhip_ctx *c) {
   }
   {
     StageTimer timer(c, VKRHIP_TIMER_SORT);
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 4096);
+    // resident blocks that take tiles by ticket (four 256-thread blocks per CU at most)
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 1024);
+    if (++c->sort_serial == 0u) c->sort_serial = 1u;
+    SortArgs s{};
+    s.state = c->sort_state();
+    s.status = c->sort_status.p;
+    s.counters = c->counters();
+    s.tiles_stride = c->sort_tiles_stride;
+    s.serial = c->sort_serial;
+    s.keys_in = c->keys_a.p;
+    hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
     bool in_a = true;
-    for (uint32_t shift = 32; shift < 64; shift += 8) {  // four passes end in keys_a again
-      SortArgs s{};
+    for (uint32_t pass = 0; pass < (uint32_t)SORT_PASSES; ++pass) {  // four passes end in keys_a again
       s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
       s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
-      s.hist = c->hist.p;
-      s.totals = c->hist.p + (size_t)SORT_RADIX * c->sort_tiles_stride;
-      s.counters = c->counters();
-      s.tiles_stride = c->sort_tiles_stride;
-      s.shift = shift;
-      hipLaunchKernelGGL(k_radix_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-      hipLaunchKernelGGL(k_radix_scan, dim3(SORT_RADIX), dim3(SORT_BLOCK), 0, c->stream, s);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
+      s.pass = pass;
+      hipLaunchKernelGGL(k_sort_pass, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
       in_a = !in_a;
     }
     HIP_TRY(c, hipGetLastError());
@@ -1469,14 +1496,14 @@ static int launch_candidates(vkrhip_ctx *c) {
   a.cflags = c->cflags.p;
   a.rows = c->cand_rows.p;
   a.n = c->n_cand;
-  hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand, 16)), dim3(256), 0,
+  hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand * 9u, 256)), dim3(256), 0,
                      c->stream, a);
   if (c->n_transmission) {
     TRY(dev_alloc(c, c->transmission_rows, c->n_transmission * 9));
     a.rows = c->transmission_rows.p;
     a.n = c->n_transmission;
     a.list = c->transmission_list.p;
-    hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_transmission, 16)), dim3(256),
+    hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_transmission * 9u, 256)), dim3(256),
                        0, c->stream, a);
   }
   HIP_TRY(c, hipGetLastError());
@@ -1532,7 +1559,15 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     }
     if (cull) TRY(launch_compaction(c));
     if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c));
-    if (stages & VKRHIP_STAGE_CANDIDATES) TRY(launch_candidates(c));
+    if (stages & VKRHIP_STAGE_CANDIDATES) {
+      TRY(launch_candidates(c));
+      // the frame's totals, for vkrhip_fill_world_payload: summed on the device and
+      // stored to pinned host memory behind everything else of the frame
+      if (++c->publish_serial == 0u) c->publish_serial = 1u;
+      hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(64), 0, c->stream,
+                         (const uint32_t *)c->counters(), c->host_counts, c->publish_serial);
+      HIP_TRY(c, hipGetLastError());
+    }
     if (stages & VKRHIP_STAGE_PACK) TRY(launch_pack(c));
     if (stages & VKRHIP_STAGE_ENCODE) TRY(launch_encode(c));
   }
@@ -1556,7 +1591,13 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
   if (c->cfg.tie_epsilon > 0.f)
     HIP_TRY(c, hipMemcpyAsync(tie_shards.data(), c->ties(), tie_shards.size() * 8,
                               hipMemcpyDeviceToHost, c->stream));
+  uint32_t sort_stalled = 0;
+  HIP_TRY(c, hipMemcpyAsync(&sort_stalled,
+                            reinterpret_cast<const char *>(c->sort_state()) + offsetof(SortState, stalled),
+                            4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (sort_stalled)
+    return fail(c, VKRHIP_ERR_STATE, "the draw-key sort gave up waiting for another tile's prefix");
   uint32_t cnt[CNT_COUNT] = {};
   for (uint32_t sh = 0; sh < STAT_SHARDS; ++sh)
     for (int k = 0; k < CNT_COUNT; ++k) cnt[k] += shards[sh * CNT_COUNT + k];
@@ -1610,6 +1651,72 @@ int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   out->packed_instances = c->packed_instances.p;
   out->visible_rows = c->visible_rows.p;
   out->commands = c->commands.p;
+  return VKRHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the reference's world-pass payload
+// ---------------------------------------------------------------------------
+static int ensure_pinned(vkrhip_ctx *c, void **p, size_t *have, size_t need) {
+  if (*have >= need && *p) return VKRHIP_OK;
+  if (*p) HIP_TRY(c, hipHostFree(*p));
+  *p = nullptr;
+  *have = 0;
+  need = std::max<size_t>(need + need / 4u, 4096);
+  HIP_TRY(c, hipHostMalloc(p, need, hipHostMallocDefault));
+  *have = need;
+  return VKRHIP_OK;
+}
+
+int vkrhip_fill_world_payload(vkrhip_ctx *c, vkrhip_world_payload *out, vkrhip_visibility_stats *stats) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  static_assert(sizeof(vkrhip_world_payload) == 88, "VkrWorldPassPayload is 88 bytes");
+  std::memset(out, 0, sizeof(*out));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (c->n_cand > VKRHIP_DRAW_CANDIDATE_CAPACITY) {  // application.h:703-711
+    out->gpu_candidate_count = VKRHIP_DRAW_CANDIDATE_CAPACITY + 1u;
+    if (stats) stats->objects_tested = VKRHIP_DRAW_CANDIDATE_CAPACITY + 1u;
+    return VKRHIP_OK;
+  }
+  const uint32_t need = VKRHIP_STAGE_CULL | VKRHIP_STAGE_TRANSPARENT | VKRHIP_STAGE_CANDIDATES;
+  if (!c->frame_ran || (c->last_stages & need) != need)
+    return fail(c, VKRHIP_ERR_STATE,
+                "the last frame did not run STAGE_CULL | STAGE_TRANSPARENT | STAGE_CANDIDATES");
+  TRY(bind_device(c));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the frame, and with it the published totals
+  const volatile uint32_t *hc = c->host_counts;
+  if (hc[0] != c->publish_serial)
+    return fail(c, VKRHIP_ERR_STATE, "the frame's totals were not published (serial %u, expected %u)",
+                hc[0], c->publish_serial);
+  const uint32_t n = (uint32_t)c->n_cand;
+  const uint32_t nt = (uint32_t)c->n_transmission;
+  const uint32_t t = hc[1 + CNT_TRANSPARENT];
+  TRY(ensure_pinned(c, &c->pay_candidates, &c->pay_candidates_bytes, (size_t)n * 144u));
+  TRY(ensure_pinned(c, &c->pay_transmission, &c->pay_transmission_bytes, (size_t)nt * 144u));
+  TRY(ensure_pinned(c, &c->pay_draws, &c->pay_draws_bytes, (size_t)t * 48u));
+  TRY(ensure_pinned(c, &c->pay_instances, &c->pay_instances_bytes, (size_t)t * 80u));
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->pay_candidates, c->cand_rows.p, (size_t)n * 144u, hipMemcpyDeviceToHost, c->stream));
+  if (nt) HIP_TRY(c, hipMemcpyAsync(c->pay_transmission, c->transmission_rows.p, (size_t)nt * 144u, hipMemcpyDeviceToHost, c->stream));
+  if (t) {
+    HIP_TRY(c, hipMemcpyAsync(c->pay_draws, c->draws.p, (size_t)t * 48u, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pay_instances, c->instances.p, (size_t)t * 80u, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out->gpu_candidates = n ? c->pay_candidates : nullptr;
+  out->gpu_candidate_count = n;
+  out->gpu_camera_opaque_candidate_count = hc[1 + CNT_CAMERA_OPAQUE];
+  out->gpu_shadow_candidate_count = n;  // application.h:950
+  out->transmission_gpu_candidates = nt ? c->pay_transmission : nullptr;
+  out->transmission_gpu_candidate_count = hc[1 + CNT_TRANSMISSION];
+  out->transparent_draws = t ? c->pay_draws : nullptr;
+  out->transparent_draw_count = t;
+  out->instances = t ? c->pay_instances : nullptr;
+  out->instance_count = t;
+  if (stats) {
+    stats->objects_tested = n;
+    stats->objects_culled_camera = hc[1 + CNT_CULLED_CAMERA];
+    stats->objects_without_bounds = hc[1 + CNT_WITHOUT_BOUNDS];
+  }
   return VKRHIP_OK;
 }
 

@@ -5,6 +5,7 @@
 // mat4_mul, lib/src/math/mat.h:1145-1163).
 #include "../../include/vkr_hip_scene.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -180,6 +181,71 @@ uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
   while (l + 1 < levels) level_offsets[++l] = reached;
   level_offsets[levels] = n;
   return levels;
+}
+
+int vkrhip_shard_hierarchy(const uint32_t *parent, uint64_t n, const uint64_t *level_offsets,
+                           uint32_t levels, uint32_t shards, uint32_t replicated_levels,
+                           uint64_t *out_ranges) {
+  if (!level_offsets || !out_ranges || levels == 0 || shards == 0) return VKRHIP_ERR_ARG;
+  if (level_offsets[0] != 0 || level_offsets[levels] != n) return VKRHIP_ERR_ARG;
+  if (levels > 1 && !parent) return VKRHIP_ERR_ARG;
+  const uint32_t cut = replicated_levels < levels ? replicated_levels : levels;
+  // subtrees are contiguous per level only when parents ascend with their children
+  for (uint32_t l = 1; l < levels; ++l) {
+    uint32_t last = 0;
+    for (uint64_t i = level_offsets[l]; i < level_offsets[l + 1]; ++i) {
+      const uint32_t p = parent[i];
+      if (p == VKRHIP_NO_PARENT) return VKRHIP_ERR_STATE;  // a root below the top level
+      if (p < level_offsets[l - 1] || p >= level_offsets[l] || p < last) return VKRHIP_ERR_STATE;
+      last = p;
+    }
+  }
+  auto range = [&](uint32_t s, uint32_t l) { return out_ranges + ((size_t)s * levels + l) * 2u; };
+  for (uint32_t s = 0; s < shards; ++s)
+    for (uint32_t l = 0; l < cut; ++l) {
+      range(s, l)[0] = level_offsets[l];
+      range(s, l)[1] = level_offsets[l + 1];
+    }
+  if (cut == levels) return VKRHIP_OK;
+  // weight of every node of the cut level = nodes of its subtree (bottom-up counts)
+  std::vector<uint64_t> weight;
+  try {
+    weight.assign(n - level_offsets[cut], 1);
+  } catch (...) {
+    return VKRHIP_ERR_CAPACITY;
+  }
+  const uint64_t base = level_offsets[cut];
+  for (uint32_t l = levels - 1; l > cut; --l)
+    for (uint64_t i = level_offsets[l]; i < level_offsets[l + 1]; ++i)
+      weight[parent[i] - base] += weight[i - base];
+  const uint64_t cb = level_offsets[cut], ce = level_offsets[cut + 1];
+  uint64_t total = 0;
+  for (uint64_t i = cb; i < ce; ++i) total += weight[i - base];
+  // boundaries in the cut level: shard s ends where the running weight passes (s+1)/shards
+  uint64_t run = 0, at = cb;
+  for (uint32_t s = 0; s < shards; ++s) {
+    range(s, cut)[0] = at;
+    const uint64_t goal = (total * (uint64_t)(s + 1) + shards - 1) / shards;
+    // a subtree goes to the shard in which its middle falls; the last shard takes the rest
+    while (at < ce && (s + 1 == shards || run + weight[at - base] / 2 < goal)) {
+      run += weight[at - base];
+      ++at;
+    }
+    range(s, cut)[1] = at;
+  }
+  // below the cut: the children of a contiguous range are a contiguous range
+  for (uint32_t l = cut + 1; l < levels; ++l) {
+    const uint32_t *lp = parent + level_offsets[l];
+    const uint64_t count = level_offsets[l + 1] - level_offsets[l];
+    for (uint32_t s = 0; s < shards; ++s) {
+      const uint64_t pb = range(s, l - 1)[0], pe = range(s, l - 1)[1];
+      range(s, l)[0] = level_offsets[l] + (uint64_t)(std::lower_bound(lp, lp + count, pb,
+          [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - lp);
+      range(s, l)[1] = level_offsets[l] + (uint64_t)(std::lower_bound(lp, lp + count, pe,
+          [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - lp);
+    }
+  }
+  return VKRHIP_OK;
 }
 
 }  // extern "C"

@@ -520,6 +520,46 @@ def levelize(parent):
     return order, new_parent, offsets[: levels + 1].copy()
 
 
+def shard_hierarchy(parent, level_offsets, shards: int, replicated_levels: int = 1) -> np.ndarray:
+    """Per-shard node ranges of a BFS-ordered hierarchy cut into whole subtrees
+    (vkrhip_shard_hierarchy): array (shards, levels, 2) of [begin, end)."""
+    lib = N.load()
+    parent = N.as_u32(parent)
+    level_offsets = np.ascontiguousarray(level_offsets, dtype=np.uint64)
+    levels = level_offsets.shape[0] - 1
+    out = np.zeros((shards, levels, 2), np.uint64)
+    rc = lib.vkrhip_shard_hierarchy(N.ptr(parent), parent.shape[0], N.ptr(level_offsets), levels,
+                                    shards, replicated_levels, N.ptr(out))
+    if rc != N.OK:
+        raise N.VkrHipError(rc, "the hierarchy is not in BFS order with ascending parents"
+                            if rc == N.ERR_STATE else "bad argument")
+    return out
+
+
+def shard_nodes(ranges_of_shard) -> np.ndarray:
+    """Global node indices of one shard (its ranges level by level) - the shard's
+    local numbering is the position in this array."""
+    return np.concatenate([np.arange(int(b), int(e), dtype=np.uint64) for b, e in ranges_of_shard])
+
+
+def shard_local_hierarchy(parent, ranges_of_shard):
+    """(global node index of every local node, local parent array, local level
+    offsets) of one shard."""
+    parent = N.as_u32(parent)
+    nodes = shard_nodes(ranges_of_shard)
+    sizes = np.array([int(e) - int(b) for b, e in ranges_of_shard], np.uint64)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    local_parent = np.full(nodes.shape[0], 0xFFFFFFFF, np.uint32)
+    for l in range(1, len(sizes)):
+        lb, le = int(offsets[l]), int(offsets[l + 1])
+        if le == lb:
+            continue
+        gp = parent[nodes[lb:le]].astype(np.int64)
+        pb = int(ranges_of_shard[l - 1][0])
+        local_parent[lb:le] = (gp - pb + int(offsets[l - 1])).astype(np.uint32)
+    return nodes, local_parent, offsets
+
+
 def effective_visibility(parent, spec) -> np.ndarray:
     """scene_entity_is_visible (lib/src/renderer/systems/vkr_scene_system.c:1935-1977)
     for every node of a parents-first hierarchy. spec: bit 0 has a SceneVisibility,
