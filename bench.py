@@ -14,8 +14,9 @@ flat32m (the per-GPU shard of 256M over eight GPUs), probes64 (16M, 64 views).
 With one GPU the line also carries `secondary` (the other workloads, shorter
 runs, each with its own roofline) and `dropin` (the frame with the 144-byte
 candidate rows, with and without the host copies a host-side consumer needs).
-With N > 1 every rank owns a contiguous shard of the same size (weak scaling)
-and the per-frame exchange all-gathers the visible lists and merges the sorted
+With N > 1 every rank owns a shard of about the same size (weak scaling: a
+contiguous index range of the flat workloads, whole trees of ONE hierarchy of
+N x 16M nodes for deep16m) and the per-frame exchange all-gathers the visible lists and merges the sorted
 draw-key runs.
 
 Prints ONE JSON line on rank 0.
@@ -98,10 +99,14 @@ def pmc_traffic(workload_name: str, overridden: bool, kernel: str, variant=None)
     return (total or None), os.path.relpath(paths[-1], ROOT)
 
 
-def build_scene(workload: dict, rank: int, seed: int, submeshes: int = 1):
+def build_scene(workload: dict, rank: int, seed: int, submeshes: int = 1, world: int = 1):
     from vulkan_renderer_amd import synth
     n = workload["n"] // submeshes
-    if workload["depth"] > 1:
+    if workload["depth"] > 1 and world > 1:
+        # ONE hierarchy of n * world nodes, cut into whole trees of about n nodes each
+        # (vkrhip_shard_hierarchy); this rank generates and owns shard `rank`
+        sc = synth.sharded_deep_scene(n, world, rank, depth=workload["depth"], seed=seed + 1)
+    elif workload["depth"] > 1:
         sc = synth.deep_scene(n, depth=workload["depth"], seed=seed + 1 + rank)
     else:
         sc = synth.flat_scene(n, seed=seed, first=rank * n)
@@ -120,13 +125,16 @@ def build_scene(workload: dict, rank: int, seed: int, submeshes: int = 1):
 class Setup:
     """One workload resident in HBM: scene, views, context."""
 
-    def __init__(self, name, workload, rank, local_rank, seed, submeshes):
+    def __init__(self, name, workload, rank, local_rank, seed, submeshes, world=1):
         import torch
         from vulkan_renderer_amd import HipScene, build_view_set, frustum_from_matrix
         from vulkan_renderer_amd import _native as N
         self.name, self.workload = name, workload
-        sc, vs, extra = build_scene(workload, rank, seed, submeshes)
+        sc, vs, extra = build_scene(workload, rank, seed, submeshes, world)
         n = sc.ident.shape[0]
+        # rows are numbered shard after shard
+        self.index_base = sc.meta.get("index_base", rank * n)
+        self.total = sc.meta.get("total", n * world)
         planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
         if extra is not None:
             planes = np.concatenate([planes, np.stack([frustum_from_matrix(m) for m in extra])])
@@ -134,7 +142,7 @@ class Setup:
         self.sc, self.vs, self.planes, self.required, self.n = sc, vs, planes, required, n
         self.views = planes.shape[0]
         hs = HipScene(max_nodes=sc.n, max_candidates=n, max_views=self.views, device=local_rank,
-                      source_index_base=rank * n)
+                      source_index_base=self.index_base)
         hs.set_stream(torch.cuda.current_stream().cuda_stream)
         hs.set_hierarchy(sc.parent if workload["depth"] > 1 else None, sc.level_offsets)
         hs.upload_trs(sc.pos, sc.quat, sc.scale)
@@ -345,7 +353,7 @@ def main() -> int:
             workload[key] = getattr(args, key)
     overridden = (bool(args.instances) or args.dirty != "world" or args.submeshes != 1 or
                   any(getattr(args, k) >= 0 for k in ("depth", "cascades", "probes")))
-    setup = Setup(args.workload, workload, rank, local_rank, args.seed, args.submeshes)
+    setup = Setup(args.workload, workload, rank, local_rank, args.seed, args.submeshes, world)
     hs, sc, n, views = setup.hs, setup.sc, setup.n, setup.views
     exchange = None
     if world > 1 or args.exchange:
@@ -390,7 +398,7 @@ def main() -> int:
             return 3
 
     ms_per_step = elapsed * 1e3 / args.steps
-    total_instances = n * world
+    total_instances = setup.total  # (the shards of a hierarchy differ by a few nodes)
     value = total_instances * args.steps / elapsed
 
     result = {

@@ -205,3 +205,27 @@ def test_shard_hierarchy_refuses_other_numberings():
     with pytest.raises(N.VkrHipError) as e:
         shard_hierarchy(parent, np.array([0, 2, 5], np.uint64), 2)
     assert e.value.code == N.ERR_STATE
+
+
+def test_sharded_deep_scene_is_the_whole_scene_cut_at_the_roots():
+    """synth.sharded_deep_scene (what bench.py gives every rank of a multi-GPU
+    hierarchy run): the shards partition the nodes of the whole scene, carry its
+    node data, and their local parents name the same nodes."""
+    from vulkan_renderer_amd import synth
+    whole = synth.deep_scene(4 * 20000, depth=6, seed=9, fanout=5, roots=8)
+    seen = np.zeros(whole.n, np.int32)
+    base = 0
+    for r in range(4):
+        sh = synth.sharded_deep_scene(20000, 4, r, depth=6, seed=9, fanout=5, roots=8)
+        g = sh.meta["global_nodes"].astype(np.int64)
+        seen[g] += 1
+        assert sh.meta["index_base"] == base and sh.meta["total"] == whole.n
+        base += sh.n
+        assert 0.8 * 20000 < sh.n < 1.2 * 20000
+        for name in ("pos", "quat", "scale", "ident", "matbits", "bounds"):
+            assert (getattr(sh, name) == getattr(whole, name)[g]).all(), name
+        has = sh.parent != 0xFFFFFFFF
+        assert (has == (whole.parent[g] != 0xFFFFFFFF)).all()
+        assert (g[sh.parent[has]] == whole.parent[g][has]).all()
+        assert int(sh.level_offsets[-1]) == sh.n
+    assert (seen == 1).all()

@@ -180,6 +180,35 @@ def deep_scene(n: int, depth: int = 8, seed: int = 2, fanout: int = 8, roots: in
                  meta={"kind": "deep", "n": n, "seed": seed, "sizes": sizes})
 
 
+def sharded_deep_scene(n_per_shard: int, shards: int, shard: int, depth: int = 8, seed: int = 2,
+                       fanout: int = 8, roots: int = 8, **cand_kw) -> Scene:
+    """Shard `shard` of deep_scene(n_per_shard * shards): the hierarchy is cut into
+    whole trees of about equal size (vkrhip_shard_hierarchy at the root level, so
+    `roots` >= `shards`) and only the shard's nodes are generated. Node and row
+    data are functions of the GLOBAL node index, so the shards together are the
+    whole scene; meta["index_base"] is the number of rows in the shards before
+    this one (rows are numbered shard after shard)."""
+    from .scene import shard_hierarchy, shard_local_hierarchy
+    if roots < shards:
+        raise ValueError("a cut at the root level needs at least one root per shard")
+    sizes = level_sizes(n_per_shard * shards, depth, fanout, roots)
+    parent, offsets = build_parents(sizes)
+    ranges = shard_hierarchy(parent, offsets, shards, replicated_levels=0)
+    nodes, local_parent, local_offsets = shard_local_hierarchy(parent, ranges[shard])
+    del parent
+    level = np.zeros(nodes.shape[0], np.int32)
+    for l in range(len(sizes)):
+        level[int(local_offsets[l]): int(local_offsets[l + 1])] = l
+    pos_range = (np.float32(250.0) * np.float32(0.5) ** level.astype(np.float32)).astype(np.float32)
+    pos, quat, scale = make_trs(seed, nodes, pos_range, (0.9, 1.1))
+    ident, matbits, bounds = make_candidates(seed, nodes, **cand_kw)
+    shard_sizes = (ranges[:, :, 1] - ranges[:, :, 0]).sum(axis=1)
+    return Scene(local_parent, local_offsets, pos, quat, scale, ident, matbits, bounds,
+                 meta={"kind": "deep", "n": int(nodes.shape[0]), "seed": seed, "sizes": sizes,
+                       "index_base": int(shard_sizes[:shard].sum()), "total": int(shard_sizes.sum()),
+                       "global_nodes": nodes})
+
+
 # ---- views ------------------------------------------------------------------
 def look_at(eye, center, up) -> np.ndarray:
     """Right-handed view matrix (camera looks down -Z), column-major float32.
