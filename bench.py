@@ -51,10 +51,11 @@ WORKLOADS = {
 
 # Algorithmic HBM bytes per unit for each kernel of the frame:
 #   transform: local 64 + parent index 4 (non-root) + flags 1+1 + world 64
-#   classify : world 64 + sphere 16 + flags 4 in; visibility byte 1 out, plus 4 per
-#              surviving (instance, view) (the staged survivor index)
+#   classify : world 64 + sphere 16 + flags 4 in; visibility byte 1 out, plus the
+#              survivor masks: one bit per (instance, view) and five more per instance
+#              (four state buckets, visible blend row)
 #   fused    : both, minus the re-read of world (it is classified in registers)
-def kernel_bytes(name: str, n: int, depth: int, survivors: int, dirty_local: bool = False,
+def kernel_bytes(name: str, n: int, depth: int, views: int, dirty_local: bool = False,
                  submeshes: int = 1) -> float:
     transform = 64 + 64 + 2 + (4 if depth > 1 else 0)
     if dirty_local:  # TRS 48 in instead of the cached local, rebuilt local 64 out
@@ -64,10 +65,11 @@ def kernel_bytes(name: str, n: int, depth: int, survivors: int, dirty_local: boo
     classify_in, classify_out = 64 / submeshes + 16 + 4 + (4 if submeshes > 1 else 0), 1
     if name == "transform":
         return (n // submeshes) * transform
+    masks = n * (views + 5) / 8
     if name == "classify":
-        return n * (classify_in + classify_out) + 4 * survivors
+        return n * (classify_in + classify_out) + masks
     if name == "fused":
-        return n * (transform + classify_in - 64 + classify_out) + 4 * survivors
+        return n * (transform + classify_in - 64 + classify_out) + masks
     raise KeyError(name)
 
 
@@ -200,8 +202,7 @@ def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden)
 
     dom_ms, dom_n = timers[dominant]
     dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
-    survivors = sum(st.visible_count for st in info.views) + info.transparent_draw_count
-    alg_bytes = kernel_bytes(dominant, n, workload["depth"], survivors, dirty == "local", submeshes)
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], setup.views, dirty == "local", submeshes)
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     traffic, traffic_source = pmc_traffic(setup.name, overridden, KERNEL_NAMES[dominant],
                                           {"fused": "true", "transform": "false"}.get(dominant))

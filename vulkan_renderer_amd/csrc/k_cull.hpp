@@ -145,14 +145,12 @@ struct CullArgs {
   uint8_t *tvis;           // transparent_visible
   uint64_t *tkey;          // sort key of visible blend rows (sparse, per candidate)
   float4 *world_bounds;    // optional (cx,cy,cz,r) per candidate
-  uint32_t *stage;         // [views + 1][stage_stride] segment-local survivor lists (candidate
-                           // indices); list `views` holds the visible blend rows
+  unsigned long long *seg_masks;  // [segment][seg_record_words(views)] survivor masks (see CullShared)
   uint32_t *seg_counts;    // [row][seg_stride] survivors of the row in the segment
-  uint32_t *seg_first;     // [seg_stride] first candidate of the segment
+  uint32_t *seg_first;     // [seg_stride] candidate of the segment's slot 0, lane 0
   uint32_t *counters;        // [STAT_SHARDS][CNT_COUNT]
   unsigned long long *ties;  // [TIE_SHARDS][CULL_MAX_VIEWS]
   uint64_t n;
-  uint64_t stage_stride;
   uint64_t seg_stride;
   uint64_t index_base;
   uint32_t views;
@@ -169,28 +167,28 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // LDS working set of one classify block, carved out of dynamic shared memory
 // (its size depends on the view count). A slot is one (round, wave) pair, i.e.
 // 64 consecutive candidates:
-//   mask  [CULL_SLOTS][views]   lanes of the slot that survive the view (ballot)
+//   mask  [views][CULL_SLOTS]   lanes of the slot that survive the view (ballot)
 //   inb   [CULL_SLOTS][4]       lanes of the slot per state bucket
 //   tmask [CULL_SLOTS]          lanes of the slot that are visible blend rows
-//   cnt   [CULL_SLOTS][rows]    (16-bit) filled when the segment ends: start position of the
-//                               slot's survivors of a row inside the segment
 //   ties  [views], stat [5]
+// mask, inb and tmask, in this order and without gaps, are the segment's record:
+// it goes to global memory as it is when the segment ends, and the gather kernel
+// turns the masks into the ordered lists once every segment's counts are scanned.
 struct CullShared {
   unsigned long long *mask;
   unsigned long long *inb;
   unsigned long long *tmask;
-  uint16_t *cnt;  // positions inside a segment: at most CULL_TILE
   uint32_t *ties;
   uint32_t *stat;
   uint32_t rows;
   uint32_t views;
 };
 
+// 64-bit words of a segment's record
+__host__ __device__ inline uint32_t seg_record_words(uint32_t views) { return CULL_SLOTS * (views + 5u); }
+
 __host__ __device__ inline size_t cull_shared_words(uint32_t views) {
-  const uint32_t rows = views * 4u + 1u;
-  static_assert(CULL_SLOTS % 2 == 0 && CULL_TILE < 65536, "16-bit positions, two to a word");
-  return 2u * ((size_t)CULL_SLOTS * views + CULL_SLOTS * 4u + CULL_SLOTS) + (size_t)(CULL_SLOTS / 2) * rows +
-         views + 5u;
+  return 2u * (size_t)seg_record_words(views) + views + 5u;
 }
 __host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
   return sizeof(uint32_t) * cull_shared_words(views);
@@ -205,8 +203,7 @@ __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
   s.mask = cull_lds64;
   s.inb = s.mask + CULL_SLOTS * views;
   s.tmask = s.inb + CULL_SLOTS * 4u;
-  s.cnt = reinterpret_cast<uint16_t *>(s.tmask + CULL_SLOTS);
-  s.ties = reinterpret_cast<uint32_t *>(s.cnt + CULL_SLOTS * s.rows);
+  s.ties = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
   s.stat = s.ties + views;
   // everything starts at zero: slots a block does not run must read as "nobody survives"
   const uint32_t total = (uint32_t)cull_shared_words(views);
@@ -378,7 +375,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     if (!TIES && !HZB) {
       const unsigned long long mp =
           gate_mask & __ballot((cf & req) == req) & (__ballot(inside) | unbounded_mask);
-      if (leader) s.mask[slot * a.views + v] = mp;
+      if (leader) s.mask[v * CULL_SLOTS + slot] = mp;
       continue;
     }
     bool pass = gate && (cf & req) == req;
@@ -407,31 +404,23 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
       if (leader && mocc) atomicAdd(&s.stat[4], (uint32_t)__popcll(mocc));
     }
     const unsigned long long mp = __ballot(pass);
-    if (leader) s.mask[slot * a.views + v] = mp;
+    if (leader) s.mask[v * CULL_SLOTS + slot] = mp;
   }
   return (bucket & 0xfu) | (tv ? 0x10u : 0u);
 }
 
-// Ends a segment: turns the slot counts into start positions, stores the row
-// counts, packs the survivors into the segment's stretch of the staging lists
-// and flushes the statistics. `packed` holds classify_candidate's return value
-// of the thread's candidate in round r in bits [8r, 8r+5); candidate (round r,
-// thread t) is segment-relative index `rel0 + 256 r + t`, the segment's staging
-// stretch starts at candidate `first`, and rel0 = (tile start) - first may be
-// "negative" (wraps): only survivors' indices are formed.
+// Ends a segment: stores the survivor counts of every row (one column of the
+// count table), the segment's record and the statistics. Slot k, lane j of the
+// record is candidate `origin + 64 k + j` (`origin` may lie before the level's
+// first candidate: such lanes survive nowhere).
 template <bool TIES>
 __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s, uint64_t seg,
-                                               uint64_t first, uint32_t tile_to_first,
-                                               uint32_t packed) {
+                                               uint32_t origin) {
   const uint32_t t = threadIdx.x;
-  const uint32_t lane = lane_id();
-  const uint32_t wave = t >> 6;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   __syncthreads();
-  // Sixteen lanes per row: the slot's survivors of the row (its view's mask cut
-  // to the row's bucket), then an exclusive prefix over the (round, wave) slots
-  // in candidate order. A wave holds the four bucket rows of one view, so the
-  // starts of buckets 1-3 behind bucket 0 come from three shuffles.
+  // sixteen lanes per row, one per slot: the slot's survivors of the row (its
+  // view's mask cut to the row's bucket), summed over the slots
+  static_assert(CULL_SLOTS == 16, "row reduction below");
   for (uint32_t r0 = 0; r0 < s.rows; r0 += CULL_BLOCK / CULL_SLOTS) {
     const uint32_t slot = t % CULL_SLOTS;
     const uint32_t r = r0 + t / CULL_SLOTS;
@@ -439,63 +428,19 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     uint32_t c = 0u;
     if (live)
       c = r < a.views * 4u
-              ? (uint32_t)__popcll(s.mask[slot * a.views + (r >> 2)] & s.inb[slot * 4u + (r & 3u)])
+              ? (uint32_t)__popcll(s.mask[(r >> 2) * CULL_SLOTS + slot] & s.inb[slot * 4u + (r & 3u)])
               : (uint32_t)__popcll(s.tmask[slot]);
-    uint32_t incl = c;
 #pragma unroll
-    for (uint32_t d = 1; d < CULL_SLOTS; d <<= 1) {
-      const uint32_t u = __shfl_up(incl, d, CULL_SLOTS);
-      if (slot >= d) incl += u;
-    }
-    const uint32_t t0 = __shfl(incl, 15, 64), t1 = __shfl(incl, 31, 64), t2 = __shfl(incl, 47, 64);
-    const uint32_t b = lane >> 4;  // bucket of the row inside its view
-    const uint32_t bucket_start = (b > 0u ? t0 : 0u) + (b > 1u ? t1 : 0u) + (b > 2u ? t2 : 0u);
-    if (live) {
-      s.cnt[slot * s.rows + r] = (uint16_t)(bucket_start + incl - c);
-      if (slot == CULL_SLOTS - 1u) a.seg_counts[(uint64_t)r * a.seg_stride + seg] = incl;
-    }
+    for (uint32_t d = CULL_SLOTS / 2; d != 0u; d >>= 1) c += __shfl_xor(c, d, CULL_SLOTS);
+    if (live && slot == 0u) a.seg_counts[(uint64_t)r * a.seg_stride + seg] = c;
   }
-  if (t == 0) a.seg_first[seg] = (uint32_t)first;
-  __syncthreads();
-
-  // View by view, the four rounds of the thread side by side: their mask reads
-  // are independent, so a view costs one LDS round trip, not four.
-  unsigned long long below[CULL_ROUNDS];  // lower lanes of the slot holding this lane's bucket
-  const uint16_t *start[CULL_ROUNDS];
-  uint32_t rel[CULL_ROUNDS];
-#pragma unroll
-  for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
-    const uint32_t bucket = (packed >> (8u * round)) & 0xfu;
-    const uint32_t slot = round * (CULL_BLOCK / 64u) + wave;
-    rel[round] = round * CULL_BLOCK + t - tile_to_first;  // candidate index - first
-    below[round] = bucket < 4u ? s.inb[slot * 4u + bucket] & lt_mask : 0ull;
-    start[round] = s.cnt + slot * s.rows + (bucket & 3u);
-  }
-  for (uint32_t v = 0; v < a.views; ++v) {
-    unsigned long long mp[CULL_ROUNDS];
-#pragma unroll
-    for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round)
-      mp[round] = s.mask[(round * (CULL_BLOCK / 64u) + wave) * a.views + v];  // the same for the whole wave
-    uint32_t *list = a.stage + (uint64_t)v * a.stage_stride + first;
-#pragma unroll
-    for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
-      if (mp[round] == 0ull) continue;  // wave-uniform
-      if ((mp[round] >> lane) & 1ull) {
-        const uint32_t pos = start[round][v * 4u] + (uint32_t)__popcll(mp[round] & below[round]);
-        list[pos] = (uint32_t)first + rel[round];
-      }
-    }
-  }
-#pragma unroll
-  for (uint32_t round = 0; round < (uint32_t)CULL_ROUNDS; ++round) {
-    if ((packed >> (8u * round)) & 0x10u) {  // a visible blend row
-      const uint32_t slot = round * (CULL_BLOCK / 64u) + wave;
-      const unsigned long long mt = s.tmask[slot];
-      const uint32_t pos = s.cnt[slot * s.rows + a.views * 4u] + (uint32_t)__popcll(mt & lt_mask);
-      a.stage[(uint64_t)a.views * a.stage_stride + first + pos] = (uint32_t)first + rel[round];
-    }
+  {
+    const uint32_t words = seg_record_words(a.views);
+    unsigned long long *record = a.seg_masks + seg * words;
+    for (uint32_t k = t; k < words; k += CULL_BLOCK) record[k] = s.mask[k];
   }
   if (t == 0) {
+    a.seg_first[seg] = origin;
     uint32_t *shard = a.counters + stat_shard();
     if (s.stat[0]) atomicAdd(&shard[CNT_WITHOUT_BOUNDS], s.stat[0]);
     if (s.stat[1]) atomicAdd(&shard[CNT_CULLED_CAMERA], s.stat[1]);
@@ -510,10 +455,15 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
                   (unsigned long long)s.ties[r]);
 }
 
-// A segment without candidates still owns a column of the count table.
+// A segment without candidates still owns a column of the count table and a
+// record (nobody survives).
 __device__ __forceinline__ void segment_empty(const CullArgs &a, uint64_t seg) {
   for (uint32_t r = threadIdx.x; r < a.views * 4u + 1u; r += blockDim.x)
     a.seg_counts[(uint64_t)r * a.seg_stride + seg] = 0u;
+  const uint32_t words = seg_record_words(a.views);
+  unsigned long long *record = a.seg_masks + seg * words;
+  for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) record[k] = 0ull;
+  if (threadIdx.x == 0) a.seg_first[seg] = 0u;
 }
 
 // Stand-alone classify: one block per segment of 1024 candidates, four rounds of
@@ -528,7 +478,6 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
   const uint64_t seg = blockIdx.x;
   const uint64_t first = seg * CULL_TILE;
   const uint64_t last = a.n - 1u;  // n > 0: the grid has a block per segment
-  uint32_t packed = 0u;
   __syncthreads();  // accumulators cleared
 
   // all rounds' small inputs are requested up front (clamped, unconditional)
@@ -573,11 +522,9 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
       m.c[2] = p[2];
       m.c[3] = p[3];
     }
-    packed |= classify_candidate<TIES, BOUNDS_OUT, HZB>(a, s, (uint32_t)round, i, valid, m,
-                                                        ls_r[round], cf)
-              << (8 * round);
+    classify_candidate<TIES, BOUNDS_OUT, HZB>(a, s, (uint32_t)round, i, valid, m, ls_r[round], cf);
   }
-  segment_finish<TIES>(a, s, seg, first, 0u, packed);
+  segment_finish<TIES>(a, s, seg, (uint32_t)first);
 }
 
 // ---------------------------------------------------------------------------
@@ -774,7 +721,7 @@ __device__ __forceinline__ CompactionState prefix_state(const uint32_t *totals4,
 }
 
 struct GatherArgs {
-  const uint32_t *stage;        // [views + 1][stage_stride]
+  const unsigned long long *seg_masks;  // [segment][seg_record_words(views)]
   const uint32_t *seg_offsets;  // [row][seg_stride], from k_scan
   const uint32_t *seg_first;
   const uint32_t *row_totals;
@@ -784,34 +731,42 @@ struct GatherArgs {
   uint32_t *visible;        // [view][visible_stride]
   uint64_t *keys;           // compacted sort keys of the visible blend rows
   uint64_t segments;
-  uint64_t stage_stride;
   uint64_t seg_stride;
   uint64_t visible_stride;
   uint64_t transparent_capacity;
   uint64_t index_base;
+  uint64_t candidates;      // n > 0
   uint32_t views;
   uint32_t partition_capacity;
 };
 
 constexpr int GATHER_BLOCK = 256;  // four waves, one segment each
-constexpr int GATHER_UNROLL = 4;
+constexpr uint32_t GATHER_SPARSE_LIMIT = 384;  // survivors of a (segment, view) written bit by bit
 
-__host__ __device__ inline size_t gather_shared_bytes(uint32_t views) {
-  return sizeof(uint32_t) * 3u * (size_t)(views * 4u + 1u) * (GATHER_BLOCK / 64);
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, uint32_t src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64);
+  const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, uint32_t uniform_src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)uniform_src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)uniform_src);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-// One wave per segment. The lanes first work out, for every (view, bucket) row,
-// how many staged survivors the segment has (next offset - own offset), where
-// the run sits in the staging list (buckets of a view back to back) and where it
-// goes (bucket start + scanned offset, clamped to the partition capacity); then
-// all runs are copied as one flat list of entries. The visible blend rows take
-// their sort keys along.
+// One wave per segment: turns the segment's survivor masks into its stretch of
+// every view's visible list. For one view the lanes stand for the 64 (bucket,
+// slot) pairs, bucket-major - the order of the list - so a wave scan of the
+// pairs' survivor counts gives every pair its position behind the segment's
+// scanned offset. Few survivors (the usual case) are then written pair by pair,
+// each lane walking the set bits of its own mask; many are written slot by slot
+// with one lane per candidate, 64 consecutive entries per store. Everything a
+// step needs is requested a step ahead.
 __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
-  extern __shared__ uint32_t gather_lds[];
+  static_assert(CULL_SLOTS == 16, "lane layouts below");
   const uint32_t t = threadIdx.x;
   const uint32_t lane = lane_id();
   const uint32_t wave = t >> 6;
-  const uint32_t rows = a.views * 4u + 1u;
   const uint32_t vrows = a.views * 4u;
   if (blockIdx.x == 0)
     for (uint32_t v = t; v < a.views; v += GATHER_BLOCK)
@@ -819,90 +774,137 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
 
   const uint64_t seg = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
   if (seg >= a.segments) return;  // wave-uniform; no block-wide barrier below
-  uint32_t *e_start = gather_lds + wave * 3u * rows;  // first flat entry of the row
-  uint32_t *e_src = e_start + rows;                   // staging position of the row's run
-  uint32_t *e_dst = e_src + rows;                     // output slot of the row's run
-  const uint32_t first = a.seg_first[seg];
-  const bool last_seg = seg + 1u == a.segments;
+  const unsigned long long *record = a.seg_masks + seg * seg_record_words(a.views);
+  // (the same address, known to be the same for the whole wave: scalar loads)
+  const unsigned long long *uniform_record =
+      a.seg_masks + (((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seg >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seg)) *
+                        seg_record_words(a.views);
+  const uint32_t slot = lane & 15u, bucket = lane >> 4;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-  uint32_t flat = 0u;       // running number of entries (wave-uniform)
-  uint32_t t_count = 0u, t_offset = 0u;
-  for (uint32_t r0 = 0; r0 < rows; r0 += 64u) {
-    const uint32_t r = r0 + lane;
-    const bool live = r < rows;
-    const uint32_t rc = live ? r : rows - 1u;
-    const uint32_t off = a.seg_offsets[(uint64_t)rc * a.seg_stride + seg];
-    const uint32_t nxt = last_seg ? a.row_totals[rc] : a.seg_offsets[(uint64_t)rc * a.seg_stride + seg + 1u];
-    uint32_t cnt = live ? nxt - off : 0u;
-    // staging: the buckets of a view lie back to back (four lanes per view)
-    uint32_t before = 0u;
+  // What the wave needs for four views, requested in one go: lane -> (view v0 +
+  // lane / 16, slot lane % 16) for the masks; lane j < 16 -> row 4 v0 + j for the
+  // row's scanned offset and the four bucket totals of the row's view.
+  struct Chunk {
+    unsigned long long masks;
+    uint32_t row, offset, total[4];
+  };
+  auto request = [&](uint32_t v0) {
+    Chunk c;
+    c.masks = record[min(v0 + bucket, a.views - 1u) * CULL_SLOTS + slot];
+    c.row = min(v0 * 4u + (lane & 15u), vrows - 1u);
+    c.offset = a.seg_offsets[(uint64_t)c.row * a.seg_stride + seg];
 #pragma unroll
-    for (uint32_t d = 1; d < 4u; ++d) {
-      const uint32_t u = __shfl_up(cnt, d, 4);
-      if ((lane & 3u) >= d) before += u;
-    }
-    // output: start of the bucket inside the view's list (as prefix_state lays the
-    // buckets out), then the scanned offset
-    uint32_t range = 0u, kept = 0u;
-    if (live && r < vrows) {
-      for (uint32_t b = 0; b < (r & 3u); ++b)
-        range += bucket_room(a.row_totals[(r & ~3u) + b], a.partition_capacity, a.visible_stride, range);
-      kept = bucket_room(a.row_totals[r], a.partition_capacity, a.visible_stride, range);
-    }
-    if (r == vrows) {  // the transparent row: copied with its keys below
-      t_count = cnt;
-      t_offset = off;
-      cnt = 0u;
-    } else if (live) {
-      // entries beyond the partition capacity or the list capacity are dropped
-      cnt = min(cnt, kept > off ? kept - off : 0u);
-    }
-    const uint32_t incl = wave_inclusive_scan(cnt);
-    if (live) {
-      e_start[r] = flat + incl - cnt;
-      e_src[r] = first + before;
-      e_dst[r] = range + off;
-    }
-    flat += (uint32_t)__shfl((int)incl, 63, 64);
-  }
-  __builtin_amdgcn_wave_barrier();  // the row table is read by other lanes of the wave
-  t_count = (uint32_t)__shfl((int)t_count, (int)(vrows & 63u), 64);
-  t_offset = (uint32_t)__shfl((int)t_offset, (int)(vrows & 63u), 64);
+    for (uint32_t b = 0; b < 4u; ++b) c.total[b] = a.row_totals[(c.row & ~3u) + b];
+    return c;
+  };
+  Chunk cur = request(0u);
+  const uint32_t origin = a.seg_first[seg];
+  const unsigned long long in_bucket = record[CULL_SLOTS * a.views + slot * 4u + bucket];
+  // (a set bit always stands for a candidate; the clamp keeps the loads inside the
+  // arrays whatever a record holds)
+  const uint32_t last_candidate = (uint32_t)(a.candidates - 1u);
+  auto source_row = [&](uint32_t candidate) -> uint32_t {
+    return a.remap ? a.remap[min(candidate, last_candidate)] : (uint32_t)(a.index_base + candidate);
+  };
 
-  // flat copy: entry e belongs to the last row whose first entry is <= e. Four
-  // entries per lane and step, so that four staging reads are in flight before
-  // the first store needs its value.
-  for (uint32_t e0 = lane; e0 < flat; e0 += 64u * GATHER_UNROLL) {
-    uint32_t idx[GATHER_UNROLL];
-    uint64_t out[GATHER_UNROLL];
+  // The visible blend rows, one lane per candidate, slot by slot: the sort keys
+  // of all sixteen slots are requested before the first one is stored.
+  {
+    const unsigned long long blend = record[CULL_SLOTS * (a.views + 4u) + slot];  // lane k < 16: slot k
+    uint64_t p = a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg];
+    uint64_t key[CULL_SLOTS];
 #pragma unroll
-    for (int u = 0; u < GATHER_UNROLL; ++u) {
-      const uint32_t e = min(e0 + 64u * (uint32_t)u, flat - 1u);  // clamped: the load is unconditional
-      uint32_t lo = 0u, hi = vrows;  // rows [lo, hi) still possible; e_start is non-decreasing
-      while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (e_start[mid] <= e) lo = mid; else hi = mid;
+    for (uint32_t k = 0; k < (uint32_t)CULL_SLOTS; ++k) {
+      const unsigned long long m = readlane64(blend, k);
+      key[k] = 0ull;
+      if (m == 0ull) continue;  // wave-uniform
+      if ((m >> lane) & 1ull) key[k] = a.tkey[min(origin + k * 64u + lane, last_candidate)];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)CULL_SLOTS; ++k) {
+      const unsigned long long m = readlane64(blend, k);
+      if (m == 0ull) continue;  // wave-uniform
+      if ((m >> lane) & 1ull) {
+        const uint64_t pos = p + (uint32_t)__popcll(m & lt_mask);
+        if (pos < a.transparent_capacity) a.keys[pos] = key[k];
       }
-      const uint32_t k = e - e_start[lo];
-      const uint32_t v = lo >> 2;
-      idx[u] = a.stage[(uint64_t)v * a.stage_stride + e_src[lo] + k];
-      out[u] = (uint64_t)v * a.visible_stride + e_dst[lo] + k;
+      p += (uint32_t)__popcll(m);
     }
-    if (a.remap) {
-#pragma unroll
-      for (int u = 0; u < GATHER_UNROLL; ++u) idx[u] = a.remap[idx[u]];
-    } else {
-#pragma unroll
-      for (int u = 0; u < GATHER_UNROLL; ++u) idx[u] = (uint32_t)(a.index_base + idx[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < GATHER_UNROLL; ++u)
-      if (e0 + 64u * (uint32_t)u < flat) a.visible[out[u]] = idx[u];
   }
-  for (uint32_t k = lane; k < t_count; k += 64u) {
-    const uint64_t pos = (uint64_t)t_offset + k;
-    if (pos < a.transparent_capacity)
-      a.keys[pos] = a.tkey[a.stage[(uint64_t)a.views * a.stage_stride + first + k]];
+
+  for (uint32_t v0 = 0; v0 < a.views; v0 += 4u) {
+    const Chunk c = cur;
+    if (v0 + 4u < a.views) cur = request(v0 + 4u);  // in flight while this chunk is written
+    // where the row's bucket starts inside its view's list and how much of it is
+    // kept (as prefix_state lays the buckets out)
+    uint32_t row_start = 0u, row_kept = 0u;
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) {
+      const uint32_t room = bucket_room(c.total[b], a.partition_capacity, a.visible_stride, row_start);
+      if (b == (c.row & 3u)) row_kept = room;
+      if (b < (c.row & 3u)) row_start += room;
+    }
+
+    const uint32_t in_chunk = min(4u, a.views - v0);
+    for (uint32_t j = 0; j < in_chunk; ++j) {  // wave-uniform
+      const unsigned long long mine = shfl64(c.masks, j * 16u + slot) & in_bucket;
+      const uint32_t count = (uint32_t)__popcll(mine);
+      const uint32_t incl = wave_inclusive_scan(count);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (total == 0u) continue;
+      const uint32_t excl = incl - count;
+      const uint32_t bucket_first = (uint32_t)__shfl((int)excl, (int)(lane & 48u), 64);
+      // position inside the bucket (before the clamp), start of the bucket, entries kept
+      uint32_t p = (uint32_t)__shfl((int)c.offset, (int)(j * 4u + bucket), 64) + (excl - bucket_first);
+      const uint32_t start = (uint32_t)__shfl((int)row_start, (int)(j * 4u + bucket), 64);
+      const uint32_t kept = (uint32_t)__shfl((int)row_kept, (int)(j * 4u + bucket), 64);
+      uint32_t *list = a.visible + (uint64_t)(v0 + j) * a.visible_stride;
+      if (total <= GATHER_SPARSE_LIMIT) {  // wave-uniform
+        unsigned long long left = mine;
+        while (__ballot(left != 0ull) != 0ull) {
+          if (left != 0ull) {
+            const uint32_t bit = (uint32_t)__ffsll((long long)left) - 1u;
+            left &= left - 1ull;
+            if (p < kept) list[start + p] = source_row(origin + slot * 64u + bit);
+            ++p;
+          }
+        }
+      } else {
+        // one lane per candidate, slot by slot; the slot's masks are the same for the
+        // whole wave (scalar values), so a lane's place among its bucket's survivors
+        // is a masked bit count
+        uint32_t base[4], limit[4];
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {
+          const uint32_t row_lane = j * 4u + b;
+          const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)row_start, (int)row_lane);
+          base[b] = first + (uint32_t)__builtin_amdgcn_readlane((int)c.offset, (int)row_lane);
+          limit[b] = first + (uint32_t)__builtin_amdgcn_readlane((int)row_kept, (int)row_lane);
+        }
+        // (constant address space: nothing in this kernel writes the records)
+        const uniform_ptr<unsigned long long> slot_buckets = as_uniform(uniform_record + CULL_SLOTS * a.views);
+#pragma unroll 2
+        for (uint32_t k = 0; k < (uint32_t)CULL_SLOTS; ++k) {
+          const unsigned long long m = readlane64(c.masks, j * 16u + k);
+          if (m == 0ull) continue;  // wave-uniform
+          uint32_t pos = 0u, end = 0u;
+#pragma unroll
+          for (uint32_t b = 0; b < 4u; ++b) {
+            const unsigned long long mb = m & slot_buckets[k * 4u + b];
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(
+                (uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+            if ((mb >> lane) & 1ull) {
+              pos = base[b] + below;
+              end = limit[b];
+            }
+            base[b] += (uint32_t)__popcll(mb);
+          }
+          if (pos < end) list[pos] = source_row(origin + k * 64u + lane);
+        }
+      }
+    }
   }
 }
 

@@ -6,7 +6,7 @@
 // (world[] is an output) and never re-read by a separate cull launch. Per node
 // the HBM traffic is local 64 B + flags 1 B in, world 64 B + flags 1 B out,
 // sphere 16 B + candidate word 4 B in, visibility byte out (+ parent index 4 B
-// below the root level) and 4 B per surviving (node, view).
+// below the root level) and one bit per (node, view) of survivor masks.
 //
 // A block owns one 1024-node count tile (aligned to 1024 in the global node
 // index) and walks it in four rounds of 256 nodes (small levels: half or a
@@ -28,7 +28,7 @@
 // loads, columns out before the stores. Below the root level the parents of the
 // wave's nodes arrive as one prefetched window (FusedParent).
 // The only block-wide barriers are the one after the LDS tables are cleared and
-// those of the end-of-segment packing.
+// the one before the segment's masks and counts are stored.
 #pragma once
 #include "k_cull.hpp"
 #include "k_transform.hpp"
@@ -315,13 +315,12 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
     own_sgprs(a.c.tvis);
     own_sgprs(a.c.tkey);
     own_sgprs(a.c.world_bounds);
-    own_sgprs(a.c.stage);
+    own_sgprs(a.c.seg_masks);
     own_sgprs(a.c.seg_counts);
     own_sgprs(a.c.seg_first);
     own_sgprs(a.c.counters);
     own_sgprs(a.c.ties);
     own_sgprs(a.c.n);
-    own_sgprs(a.c.stage_stride);
     own_sgprs(a.c.seg_stride);
     own_sgprs(a.c.index_base);
   }
@@ -373,7 +372,6 @@ k_propagate_classify(FusedArgs a) {
   if (t == 0) s_updated = 0u;
   CullShared s{};
   if (CULL) s = cull_shared_init(a.c.views);
-  uint32_t packed = 0u;  // per round: state bucket and blend-row visibility of this thread's candidate
 
   // rounds of the tile that overlap the level (block-uniform)
   auto active = [&](int r) {
@@ -599,16 +597,15 @@ k_propagate_classify(FusedArgs a) {
     world.c[1] = w1;
     world.c[2] = w2;
     world.c[3] = w3;
-    packed |= classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, world,
-                                                   make_float4(hd.ls.x, hd.ls.y, hd.ls.z, hd.ls.w), cf)
-              << (8 * round);
+    classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, world,
+                                         make_float4(hd.ls.x, hd.ls.y, hd.ls.z, hd.ls.w), cf);
   }
   {
     const uint32_t wave_updates = wave_inclusive_scan(updated_here);
     if ((t & 63u) == 63u && wave_updates) atomicAdd(&s_updated, wave_updates);
   }
   if (CULL)
-    segment_finish<TIES>(a.c, s, seg, tile_base + lo, lo, packed);
+    segment_finish<TIES>(a.c, s, seg, (uint32_t)tile_base);
   else
     __syncthreads();  // s_updated is complete
   if (t == 0 && s_updated) atomicAdd(a.t.counters + stat_shard() + CNT_NODES_UPDATED, s_updated);

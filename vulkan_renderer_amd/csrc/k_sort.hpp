@@ -240,14 +240,23 @@ struct SortArgs {
   uint32_t tiles_stride;
   uint32_t pass;               // 0..3: key bits [32 + 8 pass, 40 + 8 pass)
   uint32_t serial;             // frame serial of the status words (never 0)
+  uint32_t capacity;           // elements of keys_in / keys_out (> 0)
+  uint32_t descending;         // this pass writes its output back to front
 };
 
-// Digit histograms of all four passes in one read of the keys.
+// Digit histograms of all four passes in one read of the keys. The keys of a
+// block's first tile are requested together with the count (from clamped
+// positions), not after it.
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_hist(SortArgs a) {
   __shared__ uint32_t s_hist[SORT_PASSES][SORT_RADIX];
+  const uint32_t t = threadIdx.x;
+  const uint32_t last = a.capacity - 1u;
+  uint64_t key[SORT_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k)
+    key[k] = a.keys_in[min(blockIdx.x * SORT_TILE + (uint32_t)k * SORT_BLOCK + t, last)];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
-  const uint32_t t = threadIdx.x;
   if (blockIdx.x >= tiles) return;  // block-uniform
 #pragma unroll
   for (int p = 0; p < SORT_PASSES; ++p) s_hist[p][t] = 0u;
@@ -257,8 +266,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_hist(SortArgs a) {
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
       const uint32_t idx = base + (uint32_t)k * SORT_BLOCK + t;
+      if (tile != blockIdx.x) key[k] = a.keys_in[min(idx, last)];  // block-uniform
       if (idx < count) {
-        const uint32_t hi = (uint32_t)(a.keys_in[idx] >> 32);
+        const uint32_t hi = (uint32_t)(key[k] >> 32);
 #pragma unroll
         for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&s_hist[p][(hi >> (8 * p)) & 0xffu], 1u);
       }
@@ -280,31 +290,40 @@ __device__ __forceinline__ unsigned long long sort_status(uint32_t serial, uint3
 // One stable pass. Wave w of the block owns keys [w*512, w*512+512) of its tile
 // and walks them in 8 steps of 64 consecutive keys, so (wave, step, lane) order
 // is memory order.
+//
+// Block b starts with tile b and takes further tiles (a grid smaller than the
+// tile count) from the ticket counter, which hands out gridDim.x, gridDim.x + 1,
+// ...: the keys of the first tile, the count and the digit totals are requested
+// together when the block starts, without a ticket's round trip in front of
+// them. A tile's look-back only ever waits for lower tiles: those belong to
+// lower blocks of the grid or to earlier tickets, and the host never launches
+// more blocks than the device holds at once, so all of them are running.
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
   __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave digit counts, then bases
   __shared__ uint32_t s_wave[SORT_BLOCK / 64];
   __shared__ uint32_t s_tile;
-  const uint32_t count = a.counters[CNT_TRANSPARENT];
-  const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
   const uint32_t t = threadIdx.x;
   const uint32_t wave = t >> 6;
   const uint32_t lane = t & 63u;
   const uint32_t shift = 32u + 8u * a.pass;
-  if (blockIdx.x >= tiles) return;  // block-uniform: the grid covers the capacity
+  const uint32_t last = a.capacity - 1u;
+  uint64_t key[SORT_ITEMS];
+  {
+    const uint32_t wbase = blockIdx.x * SORT_TILE + wave * SORT_WAVE_KEYS;
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) key[k] = a.keys_in[min(wbase + (uint32_t)k * 64u + lane, last)];
+  }
+  const uint32_t my_total = a.state->hist[a.pass][t];
+  const uint32_t count = a.counters[CNT_TRANSPARENT];
+  const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
+  if (blockIdx.x >= tiles) return;  // block-uniform: the grid covers an estimate of the count
+  for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
   // keys with smaller digits come first: exclusive scan of the digit totals
   uint32_t all_keys;
-  const uint32_t digit_base = block_exclusive_scan(a.state->hist[a.pass][t], s_wave, &all_keys);
+  const uint32_t digit_base = block_exclusive_scan(my_total, s_wave, &all_keys);
   unsigned long long *status = a.status + (size_t)a.pass * a.tiles_stride * SORT_RADIX;
 
-  for (;;) {
-    __syncthreads();  // the previous tile's readers are done with the tables
-    if (t == 0) s_tile = atomicAdd(&a.state->ticket[a.pass], 1u);
-    for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= tiles) break;  // block-uniform
-
-    uint64_t key[SORT_ITEMS];
+  for (uint32_t tile = blockIdx.x;;) {
     bool valid[SORT_ITEMS];
     uint32_t rank[SORT_ITEMS];
     const uint32_t wbase = tile * SORT_TILE + wave * SORT_WAVE_KEYS;
@@ -312,7 +331,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
     for (int k = 0; k < SORT_ITEMS; ++k) {
       const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
       valid[k] = idx < count;
-      key[k] = valid[k] ? a.keys_in[idx] : 0ull;
+      if (tile != blockIdx.x) key[k] = a.keys_in[min(idx, last)];  // block-uniform
+      if (!valid[k]) key[k] = 0ull;
     }
     wave_rank<SORT_ITEMS>(key, valid, SORT_ITEMS, shift, s_whist[wave], rank);
     __syncthreads();
@@ -329,9 +349,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
     // look back: keys of this digit in the tiles before this one
     uint32_t before = 0u;
     if (tile != 0u) {
-      // eight tiles per step, nearest first: their status words are independent loads,
-      // so a step costs one memory round trip, not eight
-      constexpr uint32_t LOOK = 8;
+      // thirty-two tiles per step, nearest first: their status words are independent
+      // loads, so a step costs one memory round trip, not thirty-two
+      constexpr uint32_t LOOK = 32;
       uint32_t polls = 0u;
       bool done = false;
       for (uint32_t hi = tile; hi != 0u && !done;) {
@@ -391,14 +411,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
     for (int k = 0; k < SORT_ITEMS; ++k) {
       if (valid[k]) {
         const uint32_t digit = (uint32_t)(key[k] >> shift) & 0xffu;
-        a.keys_out[s_whist[wave][digit] + rank[k]] = key[k];
+        const uint32_t pos = s_whist[wave][digit] + rank[k];
+        a.keys_out[a.descending ? all_keys - 1u - pos : pos] = key[k];
       }
     }
+    if (tiles <= gridDim.x) break;  // block-uniform: every tile had a block of its own
+    __syncthreads();                // the tile's readers are done with the tables
+    if (t == 0) s_tile = gridDim.x + atomicAdd(&a.state->ticket[a.pass], 1u);
+    for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
+    __syncthreads();
+    tile = s_tile;
+    if (tile >= tiles) break;  // block-uniform
   }
 }
 
 struct EmitArgs {
-  const uint64_t *keys;      // ascending-sorted
+  const uint64_t *keys;      // sorted: ascending, or descending when keys_descending
   const uint32_t *counters;  // CNT_TRANSPARENT
   const float4 *world;
   const uint32_t *node;
@@ -408,6 +436,8 @@ struct EmitArgs {
   uint64_t *out_keys;  // descending
   uint32_t *out_source;
   uint64_t index_base;
+  uint32_t capacity;         // elements of keys (> 0)
+  uint32_t keys_descending;  // k_emit_transparent only
 };
 
 // vkr_picking_encode_id(SCENE, render_id), systems/vkr_picking_ids.h:35-42;
@@ -466,14 +496,22 @@ __device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32
   emit_piece_store(a, row, key, piece, emit_piece_gather(a, key, piece));
 }
 
-// Emission from the ascending-sorted key array, read backwards.
+// Emission from the sorted key array: read backwards when it is ascending; when
+// the last sort pass left it descending, a row's key does not depend on the
+// count and is requested together with it.
 __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
-  const uint32_t count = a.counters[CNT_TRANSPARENT];
   const uint32_t rows_per_block = 256u / 8u;
   const uint32_t piece = threadIdx.x & 7u;
-  for (uint32_t row = blockIdx.x * rows_per_block + (threadIdx.x >> 3); row < count;
-       row += gridDim.x * rows_per_block)
-    emit_transparent_piece(a, row, a.keys[count - 1u - row], piece);
+  const uint32_t stride = gridDim.x * rows_per_block;
+  uint32_t row = blockIdx.x * rows_per_block + (threadIdx.x >> 3);
+  uint64_t key = a.keys[min(row, a.capacity - 1u)];
+  const uint32_t count = a.counters[CNT_TRANSPARENT];
+  for (; row < count; row += stride) {
+    if (!a.keys_descending) key = a.keys[count - 1u - row];
+    const uint64_t next = a.keys[min(row + stride, a.capacity - 1u)];
+    emit_transparent_piece(a, row, key, piece);
+    key = next;
+  }
 }
 
 // Sort + emission in one launch for small counts. Sort keys are unique (the low

@@ -115,11 +115,10 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> row_totals;  // survivors per count row, written by k_scan
   // Segment tables of the compaction: a segment is the stretch of candidates one
   // classify block handled (at most 1024). Sized for the hierarchy in use.
-  DevBuf<uint32_t> stage;        // [max_views + 1][stage_stride] segment-local survivor lists
+  DevBuf<unsigned long long> seg_masks;  // [seg_stride][seg_record_words(max_views)] survivor masks
   DevBuf<uint32_t> seg_counts;   // [max_views * 4 + 1][seg_stride]
   DevBuf<uint32_t> seg_offsets;  // same shape, exclusive prefix
   DevBuf<uint32_t> seg_first;    // [seg_stride]
-  uint64_t stage_stride = 0;
   uint64_t seg_stride = 0;
   uint64_t segments = 0;  // segments of the frame being enqueued
   // Per-frame counters: two blocks of [sharded counters | tie counters]. Frames
@@ -596,8 +595,6 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->tie_eps, VKRHIP_MAX_VIEWS * 6));
     TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->camera_view, 4));
-    c->stage_stride = mc;
-    TRY(dev_alloc(c, c->stage, (size_t)(c->cfg.max_views + 1u) * mc));
     TRY(dev_alloc(c, c->tvis, mc));
     TRY(dev_alloc(c, c->frame_zero, 2u * vkrhip_ctx::kBlockBytes));
     HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, c->frame_zero.count, c->stream));
@@ -656,7 +653,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->tie_eps);
   dev_free(c->required);
   dev_free(c->camera_view);
-  dev_free(c->stage);
+  dev_free(c->seg_masks);
   dev_free(c->pub_geometries);
   dev_free(c->pub_submeshes);
   dev_free(c->pub_materials);
@@ -1156,13 +1153,12 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.tvis = c->tvis.p;
   a.tkey = c->tkey.p;
   a.world_bounds = c->world_bounds.p;
-  a.stage = c->stage.p;
+  a.seg_masks = c->seg_masks.p;
   a.seg_counts = c->seg_counts.p;
   a.seg_first = c->seg_first.p;
   a.counters = c->counters();
   a.ties = c->ties();
   a.n = c->n_cand;
-  a.stage_stride = c->stage_stride;
   a.seg_stride = c->seg_stride;
   a.index_base = c->cfg.source_index_base;
   a.views = c->views;
@@ -1235,12 +1231,16 @@ static int ensure_segments(vkrhip_ctx *c, uint64_t segments) {
   dev_free(c->seg_counts);
   dev_free(c->seg_offsets);
   dev_free(c->seg_first);
+  dev_free(c->seg_masks);
   c->seg_stride = 0;
   const uint64_t stride = need + need / 4u;  // head room for a growing scene
   const size_t rows = (size_t)c->cfg.max_views * 4u + 1u;
   TRY(dev_alloc(c, c->seg_counts, rows * stride));
   TRY(dev_alloc(c, c->seg_offsets, rows * stride));
   TRY(dev_alloc(c, c->seg_first, stride));
+  TRY(dev_alloc(c, c->seg_masks, stride * seg_record_words(c->cfg.max_views)));
+  HIP_TRY(c, hipMemsetAsync(c->seg_masks.p, 0, c->seg_masks.count * sizeof(unsigned long long), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->seg_first.p, 0, c->seg_first.count * sizeof(uint32_t), c->stream));
   c->seg_stride = stride & ~(uint64_t)3u;
   return VKRHIP_OK;
 }
@@ -1391,7 +1391,7 @@ static int launch_compaction(vkrhip_ctx *c) {
   {
     StageTimer timer(c, VKRHIP_TIMER_SCATTER);
     GatherArgs g{};
-    g.stage = c->stage.p;
+    g.seg_masks = c->seg_masks.p;
     g.seg_offsets = c->seg_offsets.p;
     g.seg_first = c->seg_first.p;
     g.row_totals = c->row_totals.p;
@@ -1401,16 +1401,15 @@ static int launch_compaction(vkrhip_ctx *c) {
     g.visible = c->visible.p;
     g.keys = c->keys_a.p;
     g.segments = segments;
-    g.stage_stride = c->stage_stride;
     g.seg_stride = c->seg_stride;
     g.visible_stride = c->visible_stride;
     g.transparent_capacity = c->tcap;
     g.index_base = c->cfg.source_index_base;
+    g.candidates = c->n_cand;
     g.views = c->views;
     g.partition_capacity = c->cfg.partition_capacity;
     const unsigned grid = (unsigned)ceil_div(segments, GATHER_BLOCK / 64);
-    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(GATHER_BLOCK), gather_shared_bytes(c->views),
-                       c->stream, g);
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(GATHER_BLOCK), 0, c->stream, g);
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
@@ -1428,6 +1427,7 @@ static EmitArgs emit_args(vkrhip_ctx *c) {
   e.out_keys = c->out_keys.p;
   e.out_source = c->out_source.p;
   e.index_base = c->cfg.source_index_base;
+  e.capacity = (uint32_t)c->tcap;
   return e;
 }
 
@@ -1454,8 +1454,9 @@ static int launch_transparent(vkrhip_ctx *c) {
   }
   {
     StageTimer timer(c, VKRHIP_TIMER_SORT);
-    // resident blocks that take tiles by ticket (four 256-thread blocks per CU at most)
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, SORT_TILE), 1024);
+    // a block per expected tile, never more than the device holds at once (four
+    // 256-thread blocks per CU); tiles beyond the grid are handed out by ticket
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, SORT_TILE), 1024);
     if (++c->sort_serial == 0u) c->sort_serial = 1u;
     SortArgs s{};
     s.state = c->sort_state();
@@ -1463,6 +1464,7 @@ static int launch_transparent(vkrhip_ctx *c) {
     s.counters = c->counters();
     s.tiles_stride = c->sort_tiles_stride;
     s.serial = c->sort_serial;
+    s.capacity = (uint32_t)c->tcap;
     s.keys_in = c->keys_a.p;
     hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
     bool in_a = true;
@@ -1470,6 +1472,7 @@ static int launch_transparent(vkrhip_ctx *c) {
       s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
       s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
       s.pass = pass;
+      s.descending = pass + 1u == (uint32_t)SORT_PASSES;  // the draw order is back to front
       hipLaunchKernelGGL(k_sort_pass, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
       in_a = !in_a;
     }
@@ -1477,8 +1480,10 @@ static int launch_transparent(vkrhip_ctx *c) {
   }
   {
     StageTimer timer(c, VKRHIP_TIMER_EMIT);
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(cap, 32), 4096);
-    hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, emit_args(c));
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, 32), 4096);
+    EmitArgs e = emit_args(c);
+    e.keys_descending = 1u;
+    hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, e);
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
