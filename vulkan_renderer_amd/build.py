@@ -17,6 +17,11 @@ EXAMPLE_BIN = os.path.join(PKG_DIR, "scene_frame")  # C host of the library (exa
 # change result bits. Square roots must be correctly rounded (sqrtf on the host).
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-ffp-contract=off",
+    # no automatic pairing of scalar float operations into packed instructions: the
+    # register moves that form the pairs cost more than the halved operation count
+    # saves (the fused kernel is 4 % faster without); the packed plane tests are
+    # written out by hand
+    "-fno-slp-vectorize",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-std=c++17",
     "-Wall", "-Wno-unused-function",
 ]

@@ -327,10 +327,13 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
 }
 
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false>
-// Four waves per SIMD: a level of 1M nodes is exactly one resident set of blocks
-// (4 per CU), and the register budget of 128 lets the compiler keep the three
-// pipeline stages apart.
-__global__ __launch_bounds__(FUSED_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+// Four waves per SIMD below the root level: a level of 1M nodes is exactly one
+// resident set of blocks (4 per CU), and the register budget of 128 lets the
+// compiler keep the three pipeline stages apart. The root-level variant has no
+// parent window and no matrix product to hold and fits five waves, which pays
+// when many views make the classification the longer part of a round.
+__global__ __launch_bounds__(FUSED_BLOCK)
+    __attribute__((amdgpu_waves_per_eu(HAS_PARENT ? 4 : 5, HAS_PARENT ? 4 : 5))) void
 k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ float4 s_par[HAS_PARENT && !TOP ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
