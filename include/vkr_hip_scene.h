@@ -67,6 +67,7 @@ extern "C" {
 #define VKRHIP_STAGE_WORLD_BOUNDS 0x10u /* instance world spheres, vkr_mesh_manager.c:315-337 */
 #define VKRHIP_STAGE_PACK 0x20u   /* vkr_vk_pack_gpu_candidates, vkr_vulkan_draws.c:344-428 */
 #define VKRHIP_STAGE_ENCODE 0x40u /* visible rows + indirect commands, deferred.slang:379-420 */
+#define VKRHIP_STAGE_CASTER_BOUNDS 0x80u /* box of the shadow casters, for VkrShadowSceneBounds */
 #define VKRHIP_STAGE_ALL 0x7u
 
 typedef struct vkrhip_ctx vkrhip_ctx;
@@ -512,6 +513,129 @@ int vkrhip_exchange_merge_static(int device, uint32_t views, const uint32_t *gat
  * render-bridge sync as well, vkr_scene_system.c:1634-1655). */
 void vkrhip_effective_visibility(const uint32_t *parent, const uint8_t *spec, uint64_t n,
                                  uint8_t *out_visible);
+
+/* The box around the world spheres of every row that casts shadows (flag
+ * VKRHIP_CAND_SHADOW_CASTER, valid bounds), accumulated by the cull of the last
+ * frame when it ran with VKRHIP_STAGE_CASTER_BOUNDS: per axis the smallest
+ * centre - radius and the largest centre + radius, each rounded once (so the
+ * result does not depend on the order of accumulation). It is what the
+ * reference's VkrShadowSceneBounds asks the application for
+ * (vkr_shadow_system.h:85-99: the caster AABB vkr_shadow_fit_relevant_caster_z
+ * clips every cascade's depth range against); copy it into
+ * vkrhip_shadow_config::scene_min / scene_max with use_scene_bounds = 1. Waits
+ * for the frame. Without any caster the box is empty (min > max). */
+int vkrhip_get_caster_bounds(vkrhip_ctx *ctx, float *out_min3, float *out_max3);
+
+/* ---- cascade fitting: the shadow views of the cull --------------------------
+ * The reference's shadow system turns the camera, the light direction and a
+ * configuration into one light view-projection matrix per cascade every frame
+ * (vkr_shadow_system_update, lib/src/renderer/systems/vkr_shadow_system.c:654-777);
+ * application_draw_frame extracts a plane set from each and the cull classifies
+ * shadow casters against them. These entry points are that step, on the host
+ * (O(cascades) float work), with the reference's names and meaning:
+ *   vkrhip_shadow_system_init / _update / _invalidate_fit_history
+ *       vkr_shadow_system_init (:591-645), vkr_shadow_system_update (:654-777),
+ *       vkr_shadow_system_invalidate_fit_history (:413-417)
+ *   vkrhip_shadow_fit_cascade          vkr_shadow_compute_cascade_matrix (:419-589)
+ *   vkrhip_shadow_fit_relevant_caster_z  vkr_shadow_fit_relevant_caster_z (:234-346)
+ *   vkrhip_shadow_quantize_extent_up   vkr_shadow_quantize_extent_up (:348-360)
+ *   vkrhip_shadow_apply_fit_hysteresis vkr_shadow_apply_fit_hysteresis (:362-396)
+ * Vector normalisation uses the reference's portable formula (vkr_simd.h:1112-
+ * 1116), not a CPU's reciprocal-square-root estimate; given the same light view
+ * and slice corners every later step is bit for bit the reference's. */
+#define VKRHIP_SHADOW_CASCADES_MAX 8u /* VKR_SHADOW_CASCADE_COUNT_MAX */
+enum { VKRHIP_CAMERA_PERSPECTIVE = 0, VKRHIP_CAMERA_ORTHOGRAPHIC = 1 };
+
+typedef struct vkrhip_shadow_fit { /* VkrShadowFit, vkr_shadow_system.h:32-39 */
+  float center_x, center_y, extent, min_z, max_z, world_units_per_texel;
+} vkrhip_shadow_fit;
+
+typedef struct vkrhip_shadow_config { /* the fields of VkrShadowConfig (:151-177) the fit reads */
+  uint32_t cascade_count;
+  uint32_t shadow_map_size;
+  float cascade_split_lambda;
+  float max_shadow_distance;
+  float cascade_guard_band_texels;
+  float cascade_guard_band_texels_per[VKRHIP_SHADOW_CASCADES_MAX];
+  float z_extension_factor;
+  float cascade_z_extension_factor_per[VKRHIP_SHADOW_CASCADES_MAX];
+  uint32_t use_constant_cascade_size;
+  float anchor_snap_texels;
+  uint32_t stabilize_cascades;
+  uint32_t use_scene_bounds; /* VkrShadowSceneBounds, :95-99 */
+  float scene_min[3];
+  float scene_max[3];
+} vkrhip_shadow_config;
+
+typedef struct vkrhip_shadow_camera { /* what the fit reads of VkrCamera */
+  uint32_t type; /* VKRHIP_CAMERA_* */
+  float position[3], forward[3], right[3], up[3];
+  float near_clip, far_clip;
+  float zoom;                           /* vertical field of view in degrees */
+  uint32_t window_width, window_height; /* aspect ratio (cached_window_width / _height) */
+  float left_clip, right_clip, bottom_clip, top_clip; /* orthographic cameras */
+} vkrhip_shadow_camera;
+
+typedef struct vkrhip_shadow_cascade { /* VkrCascadeData, :74-83 */
+  float view_projection[16];
+  float split_far;
+  float world_units_per_texel;
+  float light_space_origin[2];
+  float light_space_depth_span;
+  float bounds_center[3];
+  float bounds_radius;
+} vkrhip_shadow_cascade;
+
+typedef struct vkrhip_shadow_system { /* VkrShadowSystem with its VkrShadowFitHistory, :52-60,314-328 */
+  vkrhip_shadow_config config;
+  vkrhip_shadow_cascade cascades[VKRHIP_SHADOW_CASCADES_MAX];
+  float cascade_splits[VKRHIP_SHADOW_CASCADES_MAX + 1];
+  float light_direction[3];
+  uint32_t light_enabled;
+  vkrhip_shadow_fit history_fits[VKRHIP_SHADOW_CASCADES_MAX];
+  float history_light_direction[3];
+  uint32_t history_cascade_count;
+  uint32_t history_shadow_map_size;
+  uint32_t history_projection_convention;
+  uint32_t history_valid;
+  uint64_t history_enable_generation;
+  uint64_t enable_generation;
+  uint32_t initialized;
+  uint32_t reserved;
+} vkrhip_shadow_system;
+
+/* VKR_SHADOW_CONFIG_HIGH, the reference's default (vkr_shadow_system.h:194-217,255). */
+void vkrhip_shadow_config_high(vkrhip_shadow_config *out);
+/* config NULL: the default preset. Clamps the configuration like the reference. */
+int vkrhip_shadow_system_init(vkrhip_shadow_system *s, const vkrhip_shadow_config *config);
+void vkrhip_shadow_system_invalidate_fit_history(vkrhip_shadow_system *s);
+/* Fills s->cascades[0 .. config.cascade_count) and s->cascade_splits. With
+ * light_enabled == 0 the cascades are reset (identity matrices) and the fit
+ * history of the enabled interval is abandoned, like the reference. */
+int vkrhip_shadow_system_update(vkrhip_shadow_system *s, const vkrhip_shadow_camera *camera,
+                                uint32_t light_enabled, const float *light_direction);
+/* One cascade from a light view matrix and the eight corners of the camera
+ * frustum slice (near TL/TR/BR/BL, far TL/TR/BR/BL, 3 floats each). config
+ * supplies the scene bounds; previous_fit NULL = no hysteresis. */
+void vkrhip_shadow_fit_cascade(const float *light_view, const float *corners24,
+                               uint32_t shadow_map_size, int stabilize, float guard_band_texels,
+                               int use_constant_cascade_size, const vkrhip_shadow_config *config,
+                               float z_extension_factor, const vkrhip_shadow_fit *previous_fit,
+                               float *out_view_projection, vkrhip_shadow_fit *out_fit,
+                               float *out_light_space_origin);
+/* Returns 0 when the box and the rectangle's column do not overlap. */
+int vkrhip_shadow_fit_relevant_caster_z(const float *light_view, const float *bounds_min,
+                                        const float *bounds_max, float left, float right,
+                                        float bottom, float top, float *out_min_z, float *out_max_z);
+float vkrhip_shadow_quantize_extent_up(float extent, uint32_t shadow_map_size);
+void vkrhip_shadow_apply_fit_hysteresis(const vkrhip_shadow_fit *previous, const vkrhip_shadow_fit *raw,
+                                        vkrhip_shadow_fit *out);
+/* The view set of a frame from the camera matrices and the fitted cascades
+ * (vkrhip_build_view_set over s->cascades): planes[(1 + cascades) * 24],
+ * required_flags[1 + cascades], *views = 1 + cascades (1 while the light is off). */
+int vkrhip_shadow_build_view_set(const vkrhip_shadow_system *s, const float *view,
+                                 const float *projection, float *planes, uint32_t *required_flags,
+                                 uint32_t *views);
 
 #ifdef __cplusplus
 }

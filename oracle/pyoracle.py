@@ -14,6 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libvkr_oracle.so")
+REF_SHADOW_SO = os.path.join(HERE, "_ref", "libvkr_ref_shadow.so")
 REF_SO = os.path.join(HERE, "_ref", "libvkr_ref.so")
 
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -124,11 +125,13 @@ COMMAND_DT = np.dtype(
 
 def build(force: bool = False) -> None:
     """Compile the oracle (and the reference shim when /root/reference exists)."""
+    sources = [os.path.join(HERE, f) for f in ("vkr_oracle.c", "vkr_oracle_shadow.c", "vkr_oracle.h")]
     if force or not os.path.exists(ORACLE_SO) or (
-        os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "vkr_oracle.c"))
+        os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in sources)
     ):
         subprocess.check_call(["make", "-C", HERE, os.path.join(HERE, "libvkr_oracle.so")])
-    if os.path.isdir("/root/reference/lib/src") and (force or not os.path.exists(REF_SO)):
+    if os.path.isdir("/root/reference/lib/src") and (
+            force or not os.path.exists(REF_SO) or not os.path.exists(REF_SHADOW_SO)):
         subprocess.check_call(["make", "-C", HERE, "ref"])
 
 
@@ -671,3 +674,237 @@ class Reference:
 
 def have_reference() -> bool:
     return os.path.exists(REF_SO)
+
+
+# ---- cascade fitting ---------------------------------------------------------
+SHADOW_CASCADES_MAX = 8
+
+
+class ShadowFit(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("center_x", "center_y", "extent", "min_z", "max_z",
+                                         "world_units_per_texel")]
+
+    def tuple(self):
+        return tuple(np.float32(getattr(self, n)) for n, _ in self._fields_)
+
+
+class ShadowConfig(C.Structure):
+    _fields_ = [("cascade_count", C.c_uint32), ("shadow_map_size", C.c_uint32),
+                ("cascade_split_lambda", C.c_float), ("max_shadow_distance", C.c_float),
+                ("cascade_guard_band_texels", C.c_float),
+                ("cascade_guard_band_texels_per", C.c_float * 8),
+                ("z_extension_factor", C.c_float),
+                ("cascade_z_extension_factor_per", C.c_float * 8),
+                ("use_constant_cascade_size", C.c_uint32), ("anchor_snap_texels", C.c_float),
+                ("stabilize_cascades", C.c_uint32), ("use_scene_bounds", C.c_uint32),
+                ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3)]
+
+
+class ShadowCamera(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("position", C.c_float * 3), ("forward", C.c_float * 3),
+                ("right", C.c_float * 3), ("up", C.c_float * 3), ("near_clip", C.c_float),
+                ("far_clip", C.c_float), ("zoom", C.c_float), ("window_width", C.c_uint32),
+                ("window_height", C.c_uint32), ("left_clip", C.c_float), ("right_clip", C.c_float),
+                ("bottom_clip", C.c_float), ("top_clip", C.c_float)]
+
+
+class ShadowCascade(C.Structure):
+    _fields_ = [("view_projection", C.c_float * 16), ("split_far", C.c_float),
+                ("world_units_per_texel", C.c_float), ("light_space_origin", C.c_float * 2),
+                ("light_space_depth_span", C.c_float), ("bounds_center", C.c_float * 3),
+                ("bounds_radius", C.c_float)]
+
+
+class ShadowSystem(C.Structure):
+    _fields_ = [("config", ShadowConfig), ("cascades", ShadowCascade * 8),
+                ("cascade_splits", C.c_float * 9), ("light_direction", C.c_float * 3),
+                ("light_enabled", C.c_uint32), ("history_fits", ShadowFit * 8),
+                ("history_light_direction", C.c_float * 3), ("history_cascade_count", C.c_uint32),
+                ("history_shadow_map_size", C.c_uint32),
+                ("history_projection_convention", C.c_uint32), ("history_valid", C.c_uint32),
+                ("history_enable_generation", C.c_uint64), ("enable_generation", C.c_uint64),
+                ("initialized", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def shadow_config_high() -> ShadowConfig:
+    """VKR_SHADOW_CONFIG_HIGH (= the default), vkr_shadow_system.h:194-217."""
+    c = ShadowConfig()
+    c.cascade_count, c.shadow_map_size = 4, 2048
+    c.cascade_split_lambda, c.max_shadow_distance = 0.80, 200.0
+    c.cascade_guard_band_texels = 32.0
+    c.cascade_guard_band_texels_per[:4] = [16.0, 24.0, 32.0, 48.0]
+    c.z_extension_factor = 4.0
+    c.cascade_z_extension_factor_per[:4] = [2.0, 3.0, 4.0, 5.0]
+    c.use_constant_cascade_size, c.anchor_snap_texels, c.stabilize_cascades = 1, 16.0, 1
+    c.use_scene_bounds = 0
+    c.scene_min[:] = [-20.0, -20.0, -20.0]
+    c.scene_max[:] = [20.0, 20.0, 20.0]
+    return c
+
+
+def shadow_camera(position, forward, right, up, near_clip=0.1, far_clip=500.0, zoom=70.0,
+                  window=(1280, 720), ortho=None) -> ShadowCamera:
+    cam = ShadowCamera()
+    cam.type = 1 if ortho is not None else 0
+    cam.position[:] = [float(x) for x in position]
+    cam.forward[:] = [float(x) for x in forward]
+    cam.right[:] = [float(x) for x in right]
+    cam.up[:] = [float(x) for x in up]
+    cam.near_clip, cam.far_clip, cam.zoom = near_clip, far_clip, zoom
+    cam.window_width, cam.window_height = window
+    if ortho is not None:
+        cam.left_clip, cam.right_clip, cam.bottom_clip, cam.top_clip = ortho
+    return cam
+
+
+class _ShadowApi:
+    """The cascade-fit entry points, which the oracle (vko_ prefix) and the
+    reference shim (ref_ prefix) export with the same signatures."""
+
+    def _bind_shadow(self, L, prefix):
+        f32p, fitp = np.ctypeslib.ndpointer(np.float32, flags="C"), C.POINTER(ShadowFit)
+        cfgp, camp = C.POINTER(ShadowConfig), C.POINTER(ShadowCamera)
+        g = lambda name: getattr(L, prefix + name)  # noqa: E731
+        g("shadow_cascade_splits").argtypes = [cfgp, C.c_float, C.c_float, C.c_float, f32p]
+        g("shadow_frustum_corners").argtypes = [camp, C.c_float, C.c_float, f32p]
+        g("shadow_light_view").argtypes = [camp, cfgp, f32p, C.c_uint32, f32p]
+        g("shadow_fit_relevant_caster_z").argtypes = [f32p, f32p, f32p] + [C.c_float] * 4 + [f32p, f32p]
+        g("shadow_fit_relevant_caster_z").restype = C.c_int
+        g("shadow_quantize_extent_up").argtypes = [C.c_float, C.c_uint32]
+        g("shadow_quantize_extent_up").restype = C.c_float
+        g("shadow_apply_fit_hysteresis").argtypes = [fitp, fitp, fitp]
+        g("shadow_cascade_matrix").argtypes = [f32p, f32p, C.c_uint32, C.c_int, C.c_float, C.c_int, cfgp,
+                                               C.c_float, fitp, f32p, fitp, f32p]
+        g("mat4_inverse_rigid").argtypes = [f32p, f32p]
+        self._sh = g
+
+    def cascade_splits(self, cfg, near_clip, far_clip, lam):
+        out = np.zeros(9, np.float32)
+        self._sh("shadow_cascade_splits")(C.byref(cfg), near_clip, far_clip, lam, out)
+        return out[: cfg.cascade_count + 1] if cfg.cascade_count else out[:2]
+
+    def frustum_corners(self, cam, near_split, far_split):
+        out = np.zeros(24, np.float32)
+        self._sh("shadow_frustum_corners")(C.byref(cam), near_split, far_split, out)
+        return out.reshape(8, 3)
+
+    def light_view(self, cam, cfg, light_direction, shadow_map_size):
+        out = np.zeros(16, np.float32)
+        self._sh("shadow_light_view")(C.byref(cam), C.byref(cfg), _f32(light_direction), shadow_map_size, out)
+        return out
+
+    def fit_relevant_caster_z(self, light_view, bounds_min, bounds_max, left, right, bottom, top):
+        lo, hi = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        ok = self._sh("shadow_fit_relevant_caster_z")(_f32(light_view).reshape(16), _f32(bounds_min),
+                                                      _f32(bounds_max), left, right, bottom, top, lo, hi)
+        return bool(ok), lo[0], hi[0]
+
+    def quantize_extent_up(self, extent, shadow_map_size):
+        return np.float32(self._sh("shadow_quantize_extent_up")(extent, shadow_map_size))
+
+    def apply_fit_hysteresis(self, previous, raw):
+        out = ShadowFit()
+        self._sh("shadow_apply_fit_hysteresis")(C.byref(previous), C.byref(raw), C.byref(out))
+        return out
+
+    def cascade_matrix(self, light_view, corners, shadow_map_size, stabilize, guard_band_texels,
+                       use_constant_cascade_size, cfg, z_extension_factor, previous_fit=None):
+        vp, origin, fit = np.zeros(16, np.float32), np.zeros(2, np.float32), ShadowFit()
+        self._sh("shadow_cascade_matrix")(
+            _f32(light_view).reshape(16), _f32(corners).reshape(24), shadow_map_size, int(stabilize),
+            guard_band_texels, int(use_constant_cascade_size), C.byref(cfg), z_extension_factor,
+            None if previous_fit is None else C.byref(previous_fit), vp, C.byref(fit), origin)
+        return vp, fit, origin
+
+    def inverse_rigid(self, m):
+        out = np.zeros(16, np.float32)
+        self._sh("mat4_inverse_rigid")(_f32(m).reshape(16), out)
+        return out
+
+
+class OracleShadow(_ShadowApi):
+    """The cascade fit of the CPU oracle (vkr_oracle_shadow.c)."""
+
+    def __init__(self, path: str = ORACLE_SO):
+        self.lib = L = C.CDLL(path)
+        self._bind_shadow(L, "vko_")
+        sysp = C.POINTER(ShadowSystem)
+        L.vko_shadow_system_init.argtypes = [sysp, C.POINTER(ShadowConfig)]
+        L.vko_shadow_system_init.restype = C.c_int
+        L.vko_shadow_system_invalidate_fit_history.argtypes = [sysp]
+        L.vko_shadow_system_update.argtypes = [sysp, C.POINTER(ShadowCamera), C.c_int,
+                                               np.ctypeslib.ndpointer(np.float32, flags="C")]
+
+    def system(self, cfg):
+        s = ShadowSystem()
+        assert self.lib.vko_shadow_system_init(C.byref(s), C.byref(cfg))
+        return s
+
+    def update(self, s, cam, light_enabled, light_direction):
+        self.lib.vko_shadow_system_update(C.byref(s), C.byref(cam), int(light_enabled), _f32(light_direction))
+        return s
+
+    def invalidate(self, s):
+        self.lib.vko_shadow_system_invalidate_fit_history(C.byref(s))
+
+
+class ReferenceShadow(_ShadowApi):
+    """The reference's own cascade fit (oracle/_ref/libvkr_ref_shadow.so). Loaded
+    with lazy binding: the reference's file names a window function that only its
+    macOS and Windows builds define, and no call made here reaches it."""
+
+    def __init__(self, path: str = REF_SHADOW_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = L = C.CDLL(path, mode=os.RTLD_LAZY)
+        self._bind_shadow(L, "ref_")
+        f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+        L.ref_shadow_default_config.argtypes = [C.POINTER(ShadowConfig)]
+        L.ref_vec3_normalize.argtypes = [f32p, f32p]
+        L.ref_shadow_system_create.argtypes = [C.POINTER(ShadowConfig)]
+        L.ref_shadow_system_create.restype = C.c_void_p
+        L.ref_shadow_system_destroy.argtypes = [C.c_void_p]
+        L.ref_shadow_system_invalidate.argtypes = [C.c_void_p]
+        L.ref_shadow_system_set_stabilize.argtypes = [C.c_void_p, C.c_int]
+        L.ref_shadow_system_update.argtypes = [C.c_void_p, C.POINTER(ShadowCamera), C.c_int, f32p]
+        L.ref_shadow_system_read.argtypes = [C.c_void_p, C.POINTER(ShadowSystem)]
+        L.ref_shadow_system_poke_history.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ShadowFit)]
+
+    def default_config(self):
+        c = ShadowConfig()
+        self.lib.ref_shadow_default_config(C.byref(c))
+        return c
+
+    def normalize(self, v):
+        out = np.zeros(3, np.float32)
+        self.lib.ref_vec3_normalize(_f32(v), out)
+        return out
+
+    def system(self, cfg):
+        h = self.lib.ref_shadow_system_create(C.byref(cfg))
+        assert h
+        return h
+
+    def destroy(self, h):
+        self.lib.ref_shadow_system_destroy(h)
+
+    def update(self, h, cam, light_enabled, light_direction):
+        self.lib.ref_shadow_system_update(h, C.byref(cam), int(light_enabled), _f32(light_direction))
+
+    def read(self, h):
+        s = ShadowSystem()
+        self.lib.ref_shadow_system_read(h, C.byref(s))
+        return s
+
+    def invalidate(self, h):
+        self.lib.ref_shadow_system_invalidate(h)
+
+    def set_stabilize(self, h, on):
+        self.lib.ref_shadow_system_set_stabilize(h, int(on))
+
+    def poke_history(self, h, cascade, fit):
+        self.lib.ref_shadow_system_poke_history(h, cascade, C.byref(fit))
+
+
+def have_reference_shadow() -> bool:
+    return os.path.exists(REF_SHADOW_SO)

@@ -392,6 +392,96 @@ vko_baseline_scene *vko_baseline_create(uint64_t n_nodes, const uint32_t *parent
 uint64_t vko_baseline_frame(vko_baseline_scene *s);
 void vko_baseline_destroy(vko_baseline_scene *s);
 
+/* ------------------------------------------------------------------------
+ * Cascade fitting (vkr_shadow_system.c), vkr_oracle_shadow.c. The step in front
+ * of the cull for the shadow views: camera + light direction + configuration
+ * -> one light view-projection matrix per cascade.
+ * ---------------------------------------------------------------------- */
+#define VKO_SHADOW_CASCADES_MAX 8 /* VKR_SHADOW_CASCADE_COUNT_MAX */
+enum { VKO_CAMERA_PERSPECTIVE = 0, VKO_CAMERA_ORTHOGRAPHIC = 1 };
+
+typedef struct vko_shadow_fit { /* VkrShadowFit, vkr_shadow_system.h:32-39 */
+  float center_x, center_y, extent, min_z, max_z, world_units_per_texel;
+} vko_shadow_fit;
+
+typedef struct vko_shadow_config { /* the fields of VkrShadowConfig (:151-177) the fit reads */
+  uint32_t cascade_count;
+  uint32_t shadow_map_size;
+  float cascade_split_lambda;
+  float max_shadow_distance;
+  float cascade_guard_band_texels;
+  float cascade_guard_band_texels_per[VKO_SHADOW_CASCADES_MAX];
+  float z_extension_factor;
+  float cascade_z_extension_factor_per[VKO_SHADOW_CASCADES_MAX];
+  uint32_t use_constant_cascade_size;
+  float anchor_snap_texels;
+  uint32_t stabilize_cascades;
+  uint32_t use_scene_bounds; /* VkrShadowSceneBounds */
+  float scene_min[3];
+  float scene_max[3];
+} vko_shadow_config;
+
+typedef struct vko_shadow_camera { /* what the fit reads of VkrCamera */
+  uint32_t type;
+  float position[3], forward[3], right[3], up[3];
+  float near_clip, far_clip, zoom;
+  uint32_t window_width, window_height; /* cached_window_width / _height */
+  float left_clip, right_clip, bottom_clip, top_clip;
+} vko_shadow_camera;
+
+typedef struct vko_shadow_cascade { /* VkrCascadeData, :74-83 */
+  float view_projection[16];
+  float split_far;
+  float world_units_per_texel;
+  float light_space_origin[2];
+  float light_space_depth_span;
+  float bounds_center[3];
+  float bounds_radius;
+} vko_shadow_cascade;
+
+typedef struct vko_shadow_system { /* VkrShadowSystem + VkrShadowFitHistory */
+  vko_shadow_config config;
+  vko_shadow_cascade cascades[VKO_SHADOW_CASCADES_MAX];
+  float cascade_splits[VKO_SHADOW_CASCADES_MAX + 1];
+  float light_direction[3];
+  uint32_t light_enabled;
+  vko_shadow_fit history_fits[VKO_SHADOW_CASCADES_MAX];
+  float history_light_direction[3];
+  uint32_t history_cascade_count;
+  uint32_t history_shadow_map_size;
+  uint32_t history_projection_convention;
+  uint32_t history_valid;
+  uint64_t history_enable_generation;
+  uint64_t enable_generation;
+  uint32_t initialized;
+  uint32_t reserved;
+} vko_shadow_system;
+
+void vko_mat4_look_at(const float *eye, const float *center, const float *up, float *out);
+void vko_mat4_inverse_rigid(const float *m, float *out);
+void vko_shadow_cascade_splits(const vko_shadow_config *cfg, float near_clip, float far_clip,
+                               float lambda, float *splits);
+void vko_shadow_frustum_corners(const vko_shadow_camera *cam, float near_split, float far_split,
+                                float *corners24);
+void vko_shadow_light_view(const vko_shadow_camera *cam, const vko_shadow_config *cfg,
+                           const float *light_direction, uint32_t shadow_map_size, float *out);
+int vko_shadow_fit_relevant_caster_z(const float *light_view, const float *bounds_min,
+                                     const float *bounds_max, float left, float right, float bottom,
+                                     float top, float *out_min_z, float *out_max_z);
+float vko_shadow_quantize_extent_up(float extent, uint32_t shadow_map_size);
+void vko_shadow_apply_fit_hysteresis(const vko_shadow_fit *previous, const vko_shadow_fit *raw,
+                                     vko_shadow_fit *out);
+void vko_shadow_cascade_matrix(const float *light_view, const float *corners24,
+                               uint32_t shadow_map_size, int stabilize, float guard_band_texels,
+                               int use_constant_cascade_size, const vko_shadow_config *cfg,
+                               float z_extension_factor, const vko_shadow_fit *previous_fit,
+                               float *out_view_projection, vko_shadow_fit *out_fit,
+                               float *out_light_space_origin);
+int vko_shadow_system_init(vko_shadow_system *s, const vko_shadow_config *config);
+void vko_shadow_system_invalidate_fit_history(vko_shadow_system *s);
+void vko_shadow_system_update(vko_shadow_system *s, const vko_shadow_camera *cam, int light_enabled,
+                              const float *light_direction);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,6 @@ git -C "$ROOT" archive "$REV" vulkan_renderer_amd/csrc include | tar -x -C "$TMP
 mkdir -p "$ROOT/ab"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt \
   -fPIC -shared -std=c++17 -o "$ROOT/ab/libvkrhip_$NAME.so" \
-  "$TMP/vulkan_renderer_amd/csrc/vkrhip.hip" "$TMP/vulkan_renderer_amd/csrc/vkrhip_host.cpp"
+  "$TMP/vulkan_renderer_amd/csrc/vkrhip.hip" "$TMP"/vulkan_renderer_amd/csrc/*.cpp
 rm -rf "$TMP"
 echo "$ROOT/ab/libvkrhip_$NAME.so"

@@ -26,6 +26,7 @@ ALPHA_OPAQUE, ALPHA_CUTOUT, ALPHA_BLEND = 0, 1, 2
 STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT = 0x1, 0x2, 0x4
 STAGE_CANDIDATES, STAGE_WORLD_BOUNDS = 0x8, 0x10
 STAGE_PACK, STAGE_ENCODE = 0x20, 0x40
+STAGE_CASTER_BOUNDS = 0x80
 STAGE_ALL = 0x7
 
 TIMER_NAMES = ["transform", "classify", "fused", "scan", "scatter", "sort", "emit",
@@ -48,6 +49,11 @@ EXPORTED_SYMBOLS = [
     "vkrhip_levelize", "vkrhip_effective_visibility",
     "vkrhip_static_init", "vkrhip_exchange_merge_static",
     "vkrhip_fill_world_payload", "vkrhip_shard_hierarchy",
+    "vkrhip_shadow_config_high", "vkrhip_shadow_system_init",
+    "vkrhip_shadow_system_invalidate_fit_history", "vkrhip_shadow_system_update",
+    "vkrhip_shadow_fit_cascade", "vkrhip_shadow_fit_relevant_caster_z",
+    "vkrhip_shadow_quantize_extent_up", "vkrhip_shadow_apply_fit_hysteresis",
+    "vkrhip_shadow_build_view_set", "vkrhip_get_caster_bounds",
 ]
 
 
@@ -65,6 +71,53 @@ class Config(C.Structure):
         ("tie_epsilon", C.c_float),
         ("flags", C.c_uint32),
     ]
+
+
+class ShadowFit(C.Structure):  # vkrhip_shadow_fit
+    _fields_ = [(n, C.c_float) for n in ("center_x", "center_y", "extent", "min_z", "max_z",
+                                         "world_units_per_texel")]
+
+    def tuple(self):
+        import numpy as np
+        return tuple(np.float32(getattr(self, n)) for n, _ in self._fields_)
+
+
+class ShadowConfig(C.Structure):  # vkrhip_shadow_config
+    _fields_ = [("cascade_count", C.c_uint32), ("shadow_map_size", C.c_uint32),
+                ("cascade_split_lambda", C.c_float), ("max_shadow_distance", C.c_float),
+                ("cascade_guard_band_texels", C.c_float),
+                ("cascade_guard_band_texels_per", C.c_float * 8),
+                ("z_extension_factor", C.c_float),
+                ("cascade_z_extension_factor_per", C.c_float * 8),
+                ("use_constant_cascade_size", C.c_uint32), ("anchor_snap_texels", C.c_float),
+                ("stabilize_cascades", C.c_uint32), ("use_scene_bounds", C.c_uint32),
+                ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3)]
+
+
+class ShadowCamera(C.Structure):  # vkrhip_shadow_camera
+    _fields_ = [("type", C.c_uint32), ("position", C.c_float * 3), ("forward", C.c_float * 3),
+                ("right", C.c_float * 3), ("up", C.c_float * 3), ("near_clip", C.c_float),
+                ("far_clip", C.c_float), ("zoom", C.c_float), ("window_width", C.c_uint32),
+                ("window_height", C.c_uint32), ("left_clip", C.c_float), ("right_clip", C.c_float),
+                ("bottom_clip", C.c_float), ("top_clip", C.c_float)]
+
+
+class ShadowCascade(C.Structure):  # vkrhip_shadow_cascade
+    _fields_ = [("view_projection", C.c_float * 16), ("split_far", C.c_float),
+                ("world_units_per_texel", C.c_float), ("light_space_origin", C.c_float * 2),
+                ("light_space_depth_span", C.c_float), ("bounds_center", C.c_float * 3),
+                ("bounds_radius", C.c_float)]
+
+
+class ShadowSystem(C.Structure):  # vkrhip_shadow_system
+    _fields_ = [("config", ShadowConfig), ("cascades", ShadowCascade * 8),
+                ("cascade_splits", C.c_float * 9), ("light_direction", C.c_float * 3),
+                ("light_enabled", C.c_uint32), ("history_fits", ShadowFit * 8),
+                ("history_light_direction", C.c_float * 3), ("history_cascade_count", C.c_uint32),
+                ("history_shadow_map_size", C.c_uint32),
+                ("history_projection_convention", C.c_uint32), ("history_valid", C.c_uint32),
+                ("history_enable_generation", C.c_uint64), ("enable_generation", C.c_uint64),
+                ("initialized", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class VisibilityStats(C.Structure):
@@ -219,6 +272,23 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_exchange_merge.argtypes = [vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vkrhip_fill_world_payload.argtypes = [vp, C.POINTER(WorldPayload), C.POINTER(VisibilityStats)]
     L.vkrhip_shard_hierarchy.argtypes = [vp, u64, vp, u32, u32, u32, vp]
+    fitp, cfgp = C.POINTER(ShadowFit), C.POINTER(ShadowConfig)
+    L.vkrhip_shadow_config_high.argtypes = [cfgp]
+    L.vkrhip_shadow_config_high.restype = None
+    L.vkrhip_shadow_system_init.argtypes = [C.POINTER(ShadowSystem), cfgp]
+    L.vkrhip_shadow_system_invalidate_fit_history.argtypes = [C.POINTER(ShadowSystem)]
+    L.vkrhip_shadow_system_invalidate_fit_history.restype = None
+    L.vkrhip_shadow_system_update.argtypes = [C.POINTER(ShadowSystem), C.POINTER(ShadowCamera), u32, vp]
+    L.vkrhip_shadow_fit_cascade.argtypes = [vp, vp, u32, C.c_int, C.c_float, C.c_int, cfgp, C.c_float,
+                                            fitp, vp, fitp, vp]
+    L.vkrhip_shadow_fit_cascade.restype = None
+    L.vkrhip_shadow_fit_relevant_caster_z.argtypes = [vp, vp, vp] + [C.c_float] * 4 + [vp, vp]
+    L.vkrhip_shadow_quantize_extent_up.argtypes = [C.c_float, u32]
+    L.vkrhip_shadow_quantize_extent_up.restype = C.c_float
+    L.vkrhip_shadow_apply_fit_hysteresis.argtypes = [fitp, fitp, fitp]
+    L.vkrhip_shadow_apply_fit_hysteresis.restype = None
+    L.vkrhip_shadow_build_view_set.argtypes = [C.POINTER(ShadowSystem), vp, vp, vp, vp, vp]
+    L.vkrhip_get_caster_bounds.argtypes = [vp, vp, vp]
     L.vkrhip_static_init.argtypes = [C.c_int]
     L.vkrhip_exchange_merge_static.argtypes = [C.c_int, u32, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vkrhip_frustum_from_matrix.argtypes = [vp, vp]

@@ -132,6 +132,23 @@ __global__ __launch_bounds__(256) void k_prepare_candidates(const uint32_t *__re
   cflags[i] = f;
 }
 
+// Floats as unsigned keys in the same order (every finite value maps above 0), so
+// that a box can be accumulated with integer atomic maxima from zeroed memory:
+// words 0-2 hold the largest ~key of the low corner (i.e. the smallest value),
+// words 3-5 the largest key of the high corner. A word still 0 means "nothing".
+__host__ __device__ __forceinline__ uint32_t order_key(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__host__ __device__ __forceinline__ float order_key_value(uint32_t k) {
+  return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+  return v;
+}
+
 struct CullArgs {
   const float4 *world;     // node matrices, 4 float4 each
   const uint32_t *node;    // candidate -> node, null = identity
@@ -150,6 +167,7 @@ struct CullArgs {
   uint32_t *seg_first;     // [seg_stride] candidate of the segment's slot 0, lane 0
   uint32_t *counters;        // [STAT_SHARDS][CNT_COUNT]
   unsigned long long *ties;  // [TIE_SHARDS][CULL_MAX_VIEWS]
+  uint32_t *caster_bounds;   // optional: [6] box of the shadow casters' world spheres (see order_key)
   uint64_t n;
   uint64_t seg_stride;
   uint64_t index_base;
@@ -170,7 +188,7 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 //   mask  [views][CULL_SLOTS]   lanes of the slot that survive the view (ballot)
 //   inb   [CULL_SLOTS][4]       lanes of the slot per state bucket
 //   tmask [CULL_SLOTS]          lanes of the slot that are visible blend rows
-//   ties  [views], stat [5]
+//   ties  [views], stat [5], box [6]
 // mask, inb and tmask, in this order and without gaps, are the segment's record:
 // it goes to global memory as it is when the segment ends, and the gather kernel
 // turns the masks into the ordered lists once every segment's counts are scanned.
@@ -180,6 +198,7 @@ struct CullShared {
   unsigned long long *tmask;
   uint32_t *ties;
   uint32_t *stat;
+  uint32_t *box;  // the block's share of CullArgs::caster_bounds
   uint32_t rows;
   uint32_t views;
 };
@@ -188,7 +207,7 @@ struct CullShared {
 __host__ __device__ inline uint32_t seg_record_words(uint32_t views) { return CULL_SLOTS * (views + 5u); }
 
 __host__ __device__ inline size_t cull_shared_words(uint32_t views) {
-  return 2u * (size_t)seg_record_words(views) + views + 5u;
+  return 2u * (size_t)seg_record_words(views) + views + 5u + 6u;
 }
 __host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
   return sizeof(uint32_t) * cull_shared_words(views);
@@ -205,6 +224,7 @@ __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
   s.tmask = s.inb + CULL_SLOTS * 4u;
   s.ties = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
   s.stat = s.ties + views;
+  s.box = s.stat + 5;
   // everything starts at zero: slots a block does not run must read as "nobody survives"
   const uint32_t total = (uint32_t)cull_shared_words(views);
   for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) cull_lds[k] = 0u;
@@ -315,6 +335,18 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
 
   const uint32_t bucket = (cf >> CF_BUCKET_SHIFT) & 0xfu;
   const bool bounds_valid = (cf & CF_BOUNDS_VALID) != 0;
+  if (a.caster_bounds != nullptr) {  // wave-uniform
+    // the box around the world spheres of the rows that cast shadows
+    const bool casts = valid && bounds_valid && (cf & CF_SHADOW_CASTER) && !(cf & CF_UNPUBLISHED);
+    const float centre[3] = {c.x, c.y, c.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t lo = wave_max_u32(casts ? ~order_key(centre[k] - radius) : 0u);
+      const uint32_t hi = wave_max_u32(casts ? order_key(centre[k] + radius) : 0u);
+      if (leader && lo) atomicMax(&s.box[k], lo);
+      if (leader && hi) atomicMax(&s.box[3 + k], hi);
+    }
+  }
 
   // ordinary blend rows: application.h:790-803 (camera frustum = view 0 planes)
   const bool blend_row = valid && (cf & CF_BLEND) && !(cf & CF_TRANSMISSIVE);
@@ -453,6 +485,7 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
       if (s.ties[r])
         atomicAdd(&a.ties[(blockIdx.x % TIE_SHARDS) * CULL_MAX_VIEWS + r],
                   (unsigned long long)s.ties[r]);
+  if (a.caster_bounds != nullptr && t < 6u && s.box[t]) atomicMax(&a.caster_bounds[t], s.box[t]);
 }
 
 // A segment without candidates still owns a column of the count table and a

@@ -320,6 +320,7 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
     own_sgprs(a.c.seg_first);
     own_sgprs(a.c.counters);
     own_sgprs(a.c.ties);
+    own_sgprs(a.c.caster_bounds);
     own_sgprs(a.c.n);
     own_sgprs(a.c.seg_stride);
     own_sgprs(a.c.index_base);

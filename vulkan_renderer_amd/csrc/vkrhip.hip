@@ -131,7 +131,12 @@ struct vkrhip_ctx {
   static constexpr size_t kCountersBytes = sizeof(uint32_t) * CNT_COUNT * STAT_SHARDS;
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
   static constexpr size_t kSortStateBytes = sizeof(SortState);
-  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes + kSortStateBytes;
+  static constexpr size_t kCasterBoxBytes = sizeof(uint32_t) * 8;  // six keys, padded
+  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes + kSortStateBytes + kCasterBoxBytes;
+  uint32_t *caster_box() const {
+    return reinterpret_cast<uint32_t *>(counter_block(cur_block) + kCountersBytes + kTiesBytes + kSortStateBytes);
+  }
+  uint32_t frame_stages = 0;  // the stages of the frame being enqueued
   SortState *sort_state() const {
     return reinterpret_cast<SortState *>(counter_block(cur_block) + kCountersBytes + kTiesBytes);
   }
@@ -1158,6 +1163,7 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.seg_first = c->seg_first.p;
   a.counters = c->counters();
   a.ties = c->ties();
+  a.caster_bounds = (c->frame_stages & VKRHIP_STAGE_CASTER_BOUNDS) ? c->caster_box() : nullptr;
   a.n = c->n_cand;
   a.seg_stride = c->seg_stride;
   a.index_base = c->cfg.source_index_base;
@@ -1525,6 +1531,8 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     return fail(c, VKRHIP_ERR_STATE, "STAGE_TRANSPARENT needs STAGE_CULL in the same frame");
   if ((stages & VKRHIP_STAGE_WORLD_BOUNDS) && !(stages & VKRHIP_STAGE_CULL))
     return fail(c, VKRHIP_ERR_STATE, "STAGE_WORLD_BOUNDS needs STAGE_CULL in the same frame");
+  if ((stages & VKRHIP_STAGE_CASTER_BOUNDS) && !(stages & VKRHIP_STAGE_CULL))
+    return fail(c, VKRHIP_ERR_STATE, "STAGE_CASTER_BOUNDS needs STAGE_CULL in the same frame");
   if ((stages & (VKRHIP_STAGE_PACK | VKRHIP_STAGE_ENCODE)) && !c->published)
     return fail(c, VKRHIP_ERR_STATE, "STAGE_PACK / STAGE_ENCODE need vkrhip_set_publication");
   if ((stages & VKRHIP_STAGE_ENCODE) &&
@@ -1541,6 +1549,7 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
                   (unsigned long long)(named - 1u), (unsigned long long)nodes);
   }
   TRY(bind_device(c));
+  c->frame_stages = stages;
   const bool cull = (stages & VKRHIP_STAGE_CULL) != 0;
   const bool bounds_out = (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0;
   if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
@@ -1827,6 +1836,24 @@ int vkrhip_read_world_bounds(vkrhip_ctx *c, uint64_t first, uint64_t count, floa
   if (!c->world_bounds.p) return fail(c, VKRHIP_ERR_STATE, "STAGE_WORLD_BOUNDS has not run");
   TRY(check_range(c, first, count, std::max<uint64_t>(c->cfg.max_candidates, 1), "read_world_bounds"));
   return read_back(c, out4, c->world_bounds.p + first, count * 16);
+}
+
+int vkrhip_get_caster_bounds(vkrhip_ctx *c, float *out_min3, float *out_max3) {
+  if (!c || !out_min3 || !out_max3) return VKRHIP_ERR_ARG;
+  const uint32_t need = VKRHIP_STAGE_CULL | VKRHIP_STAGE_CASTER_BOUNDS;
+  if (!c->frame_ran || (c->last_stages & need) != need)
+    return fail(c, VKRHIP_ERR_STATE, "the last frame did not run STAGE_CASTER_BOUNDS");
+  TRY(bind_device(c));
+  uint32_t keys[6] = {};
+  TRY(read_back(c, keys, c->caster_box(), sizeof(keys)));
+  int found = 1;
+  for (int k = 0; k < 6; ++k) found = found && keys[k] != 0u;
+  for (int k = 0; k < 3; ++k) {
+    // no caster: an empty box (min above max), which the cascade fit rejects
+    out_min3[k] = found ? order_key_value(~keys[k]) : 3.402823466e+38f;
+    out_max3[k] = found ? order_key_value(keys[3 + k]) : -3.402823466e+38f;
+  }
+  return VKRHIP_OK;
 }
 
 int vkrhip_read_candidate_prep(vkrhip_ctx *c, uint64_t first, uint64_t count, float *sphere4,

@@ -337,6 +337,13 @@ class HipScene:
         self._ok(self.lib.vkrhip_read_world_bounds(self.ctx, 0, self.n_candidates, N.ptr(out)))
         return out
 
+    def caster_bounds(self):
+        """(min (3,), max (3,)) of the box around the shadow casters' world spheres
+        (the last frame ran with STAGE_CASTER_BOUNDS); min > max when there is none."""
+        lo, hi = np.empty(3, np.float32), np.empty(3, np.float32)
+        self._ok(self.lib.vkrhip_get_caster_bounds(self.ctx, N.ptr(lo), N.ptr(hi)))
+        return lo, hi
+
     def read_candidate_prep(self):
         sphere = np.empty((self.n_candidates, 4), np.float32)
         flags = np.empty(self.n_candidates, np.uint32)
