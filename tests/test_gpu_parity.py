@@ -379,3 +379,47 @@ def test_rows_must_name_nodes_of_the_scene(oracle):
         assert e.value.code == N.ERR_STATE
         hs.set_candidates(node % small, ident, matbits, bounds)
         hs.frame()
+
+
+@pytest.mark.parametrize("top_levels", ["1", "0"])
+@pytest.mark.parametrize("dirty", ["all", "subset"])
+def test_merged_top_levels_on_and_off(oracle, monkeypatch, top_levels, dirty):
+    """The small top levels of a hierarchy in one launch (every block recomputes
+    its nodes' ancestors) and as a launch per level (VKRHIP_TOP_LEVELS=0): both
+    equal the oracle over three frames, with every node moved and with only a
+    few subtrees moved (deferred dirty propagation through recomputed ancestors,
+    the two copies of the node flags swapping every frame)."""
+    synth = _synth()
+    monkeypatch.setenv("VKRHIP_TOP_LEVELS", top_levels)
+    sc = synth.deep_scene(90000, depth=8, seed=13, fanout=5, roots=7, blend_fraction=0.2)
+    vs = synth.camera_views(cascades=2, far=700.0)
+    planes, required = view_set(vs)
+    rng = np.random.default_rng(3)
+    with hip_scene_for(sc, 3) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, oracle_frame(oracle, sc, planes, required, vs.view, vs.projection), sc)
+        world = hs.read_world()
+        local = hs.read_locals()
+        for frame in range(3):
+            if dirty == "all":
+                flags = np.full(sc.n, DIRTY_WORLD, np.uint8)
+            else:  # a handful of nodes near the roots and a few leaves
+                flags = np.zeros(sc.n, np.uint8)
+                flags[rng.integers(0, 200, 5)] = DIRTY_WORLD
+                flags[rng.integers(0, sc.n, 40)] = DIRTY_WORLD
+            # moved nodes get a new local matrix (a small translation)
+            moved = np.flatnonzero(flags)
+            local = local.copy()
+            local[moved, 12] += np.float32(0.25 * (frame + 1))
+            hs.upload_locals(local)
+            hs.upload_node_flags(flags)
+            _, want_world, want_flags, dirty_list = oracle.scene_update(sc.parent, local=local, flags=flags,
+                                                                         world=world)
+            hs.frame()
+            ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, world=want_world)
+            compare_frame(hs, ref, sc, check_transform=False)
+            assert_bits_equal(hs.read_world(), want_world, f"world matrices, frame {frame}")
+            assert (hs.read_node_flags() == want_flags).all(), f"node flags, frame {frame}"
+            assert hs.frame_info().nodes_updated == dirty_list.shape[0] > 0
+            world = want_world
