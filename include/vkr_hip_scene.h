@@ -637,6 +637,36 @@ int vkrhip_shadow_build_view_set(const vkrhip_shadow_system *s, const float *vie
                                  const float *projection, float *planes, uint32_t *required_flags,
                                  uint32_t *views);
 
+/* ---- glTF node hierarchy -----------------------------------------------------
+ * "nodes" and "scenes" of a glTF 2.0 document (the JSON text of a .gltf file or
+ * of a .glb's JSON chunk) as per-node arrays in file order: what the reference
+ * gets from cgltf (vendor/cgltf.h: cgltf_node parent / children / translation /
+ * rotation / scale / matrix / mesh, cgltf_scene nodes) when it imports such a
+ * file, read by a JSON walker of the library's own. Host code.
+ *   scene      index into "scenes"; 0xffffffff = the document's "scene", else 0
+ *   capacity   room in the arrays; with fewer, info is filled and
+ *              VKRHIP_ERR_CAPACITY returned (call once with 0 to size them)
+ *   parent     glTF index of the node's parent, 0xffffffff for a root
+ *   in_scene   1 when the chosen scene reaches the node (every node when the
+ *              document has no scenes)
+ *   pos4 / quat4 (x, y, z, w) / scale4   the node's TRS, glTF defaults where absent
+ *   mesh       index into "meshes", -1 for none
+ *   has_matrix / matrix16   a node given as a column-major matrix instead
+ * Any array may be NULL. Numbers are rounded once (decimal text -> double ->
+ * float). VKRHIP_ERR_ARG: not JSON, an index out of range, a node with two
+ * parents, a cycle, a scene that lists a non-root. The parent array goes to
+ * vkrhip_levelize as it is (restricted to the scene's nodes by the caller). */
+typedef struct vkrhip_gltf_nodes {
+  uint32_t node_count;  /* "nodes" of the document */
+  uint32_t scene_count; /* "scenes" of the document */
+  uint32_t scene;       /* the scene that was read */
+  uint32_t scene_nodes; /* nodes it reaches */
+} vkrhip_gltf_nodes;
+int vkrhip_gltf_read_nodes(const char *json, uint64_t length, uint32_t scene, uint32_t capacity,
+                           vkrhip_gltf_nodes *info, uint32_t *parent, uint8_t *in_scene, float *pos4,
+                           float *quat4, float *scale4, int32_t *mesh, uint8_t *has_matrix,
+                           float *matrix16);
+
 #ifdef __cplusplus
 }
 #endif

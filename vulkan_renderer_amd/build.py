@@ -8,7 +8,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvkrhip.so")
-SOURCES = ["vkrhip.hip", "vkrhip_host.cpp", "vkrhip_shadow.cpp"]
+SOURCES = ["vkrhip.hip", "vkrhip_host.cpp", "vkrhip_shadow.cpp", "vkrhip_gltf.cpp"]
 EXAMPLE_SRC = os.path.join(os.path.dirname(PKG_DIR), "examples", "scene_frame.c")
 EXAMPLE_BIN = os.path.join(PKG_DIR, "scene_frame")  # C host of the library (examples/scene_frame.c)
 
