@@ -423,3 +423,28 @@ def test_merged_top_levels_on_and_off(oracle, monkeypatch, top_levels, dirty):
             assert (hs.read_node_flags() == want_flags).all(), f"node flags, frame {frame}"
             assert hs.frame_info().nodes_updated == dirty_list.shape[0] > 0
             world = want_world
+
+
+@pytest.mark.parametrize("shape", ["flat", "deep"])
+def test_blocks_streaming_over_tiles(oracle, monkeypatch, shape):
+    """VKRHIP_STREAM_TILES=1: levels with more tiles than the device holds blocks are
+    walked by resident blocks that take tile after tile (the pipeline runs across
+    tile boundaries, two sets of cull tables, tiles handed out by a counter).
+    Same results, two frames in a row."""
+    synth = _synth()
+    monkeypatch.setenv("VKRHIP_STREAM_TILES", "1")
+    if shape == "flat":
+        sc = synth.flat_scene(1400000 + 777, seed=5, blend_fraction=0.1)
+        vs = synth.camera_views(cascades=1)
+    else:
+        sc = synth.deep_scene(1700000, depth=3, seed=6, fanout=40, roots=30, blend_fraction=0.1)
+        vs = synth.camera_views(cascades=2, far=900.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, planes.shape[0]) as hs:
+        hs.set_views(planes, required, vs.view)
+        for _ in range(2):
+            hs.mark_all(DIRTY_WORLD)
+            hs.frame()
+            compare_frame(hs, ref, sc, check_transform=False)
+            assert_bits_equal(hs.read_world(), ref["world"], "world matrices")

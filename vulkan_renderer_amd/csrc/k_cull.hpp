@@ -209,11 +209,48 @@ __host__ __device__ inline uint32_t seg_record_words(uint32_t views) { return CU
 __host__ __device__ inline size_t cull_shared_words(uint32_t views) {
   return 2u * (size_t)seg_record_words(views) + views + 5u + 6u;
 }
-__host__ __device__ inline size_t cull_shared_bytes(uint32_t views) {
-  return sizeof(uint32_t) * cull_shared_words(views);
+// A block may hold the working set more than once (a block that walks several
+// segments alternates between two sets); a set starts on an 8-byte boundary.
+__host__ __device__ inline size_t cull_shared_set_words(uint32_t views) {
+  return (cull_shared_words(views) + 1u) & ~(size_t)1u;
+}
+__host__ __device__ inline size_t cull_shared_bytes(uint32_t views, uint32_t sets = 1) {
+  return sizeof(uint32_t) * cull_shared_set_words(views) * sets;
 }
 
-__device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
+// Set `which` of the block's working sets (no clearing).
+__device__ __forceinline__ CullShared cull_shared_set(uint32_t views, uint32_t which) {
+  extern __shared__ unsigned long long cull_lds64[];  // 8-byte aligned
+  CullShared s;
+  s.rows = views * 4u + 1u;
+  s.views = views;
+  s.mask = cull_lds64 + which * (cull_shared_set_words(views) / 2u);
+  s.inb = s.mask + CULL_SLOTS * views;
+  s.tmask = s.inb + CULL_SLOTS * 4u;
+  s.ties = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
+  s.stat = s.ties + views;
+  s.box = s.stat + 5;
+  return s;
+}
+
+// The slots of a set that the calling wave writes (slot = round * 4 + wave), set
+// back to "nobody survives": what a wave does when it enters a further segment
+// (rounds the segment does not run must read as empty). views + 5 <= 64.
+__device__ __forceinline__ void cull_clear_wave_slots(const CullShared &s) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (uint32_t r = 0; r < (uint32_t)CULL_ROUNDS; ++r) {
+    const uint32_t slot = r * (CULL_BLOCK / 64u) + wave;
+    if (lane < s.views)
+      s.mask[lane * CULL_SLOTS + slot] = 0ull;
+    else if (lane < s.views + 4u)
+      s.inb[slot * 4u + (lane - s.views)] = 0ull;
+    else if (lane == s.views + 4u)
+      s.tmask[slot] = 0ull;
+  }
+}
+
+__device__ __forceinline__ CullShared cull_shared_init(uint32_t views, uint32_t sets = 1) {
   extern __shared__ unsigned long long cull_lds64[];  // 8-byte aligned
   uint32_t *cull_lds = reinterpret_cast<uint32_t *>(cull_lds64);
   CullShared s;
@@ -226,7 +263,7 @@ __device__ __forceinline__ CullShared cull_shared_init(uint32_t views) {
   s.stat = s.ties + views;
   s.box = s.stat + 5;
   // everything starts at zero: slots a block does not run must read as "nobody survives"
-  const uint32_t total = (uint32_t)cull_shared_words(views);
+  const uint32_t total = (uint32_t)(cull_shared_set_words(views) * sets);
   for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) cull_lds[k] = 0u;
   return s;
 }
@@ -471,21 +508,37 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     unsigned long long *record = a.seg_masks + seg * words;
     for (uint32_t k = t; k < words; k += CULL_BLOCK) record[k] = s.mask[k];
   }
+  // (every accumulator is set back to zero by the thread that flushes it: a block
+  // that walks several segments uses the set again two segments later)
   if (t == 0) {
     a.seg_first[seg] = origin;
     uint32_t *shard = a.counters + stat_shard();
-    if (s.stat[0]) atomicAdd(&shard[CNT_WITHOUT_BOUNDS], s.stat[0]);
-    if (s.stat[1]) atomicAdd(&shard[CNT_CULLED_CAMERA], s.stat[1]);
-    if (s.stat[2]) atomicAdd(&shard[CNT_CAMERA_OPAQUE], s.stat[2]);
-    if (s.stat[3]) atomicAdd(&shard[CNT_TRANSMISSION], s.stat[3]);
-    if (s.stat[4]) atomicAdd(&shard[CNT_OCCLUDED], s.stat[4]);
+    const int which[5] = {CNT_WITHOUT_BOUNDS, CNT_CULLED_CAMERA, CNT_CAMERA_OPAQUE, CNT_TRANSMISSION,
+                          CNT_OCCLUDED};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const uint32_t v = s.stat[k];
+      if (v) {
+        atomicAdd(&shard[which[k]], v);
+        s.stat[k] = 0u;
+      }
+    }
   }
   if (TIES)
-    for (uint32_t r = t; r < a.views; r += blockDim.x)
-      if (s.ties[r])
-        atomicAdd(&a.ties[(blockIdx.x % TIE_SHARDS) * CULL_MAX_VIEWS + r],
-                  (unsigned long long)s.ties[r]);
-  if (a.caster_bounds != nullptr && t < 6u && s.box[t]) atomicMax(&a.caster_bounds[t], s.box[t]);
+    for (uint32_t r = t; r < a.views; r += blockDim.x) {
+      const uint32_t v = s.ties[r];
+      if (v) {
+        atomicAdd(&a.ties[(blockIdx.x % TIE_SHARDS) * CULL_MAX_VIEWS + r], (unsigned long long)v);
+        s.ties[r] = 0u;
+      }
+    }
+  if (a.caster_bounds != nullptr && t < 6u) {
+    const uint32_t v = s.box[t];
+    if (v) {
+      atomicMax(&a.caster_bounds[t], v);
+      s.box[t] = 0u;
+    }
+  }
 }
 
 // A segment without candidates still owns a column of the count table and a

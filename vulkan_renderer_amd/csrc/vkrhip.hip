@@ -132,7 +132,20 @@ struct vkrhip_ctx {
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
   static constexpr size_t kSortStateBytes = sizeof(SortState);
   static constexpr size_t kCasterBoxBytes = sizeof(uint32_t) * 8;  // six keys, padded
-  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes + kSortStateBytes + kCasterBoxBytes;
+  static constexpr uint32_t kStreamTickets = 16;  // streaming launches of a frame (one counter each)
+  static constexpr size_t kStreamBytes = sizeof(uint32_t) * kStreamTickets;
+  static constexpr size_t kBlockBytes =
+      kCountersBytes + kTiesBytes + kSortStateBytes + kCasterBoxBytes + kStreamBytes;
+  uint32_t *stream_tickets() const {
+    return reinterpret_cast<uint32_t *>(counter_block(cur_block) + kCountersBytes + kTiesBytes +
+                                        kSortStateBytes + kCasterBoxBytes);
+  }
+  uint32_t stream_used = 0;   // counters handed out this frame
+  uint32_t cu_count = 0;
+  // VKRHIP_STREAM_TILES=1: large levels are walked by resident blocks that stream over
+  // several tiles. Off by default: the state a block carries from tile to tile costs
+  // the kernel registers it does not have (scratch traffic), and it runs slower.
+  bool stream_enabled = false;
   uint32_t *caster_box() const {
     return reinterpret_cast<uint32_t *>(counter_block(cur_block) + kCountersBytes + kTiesBytes + kSortStateBytes);
   }
@@ -577,10 +590,16 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     if (r == 1 || r == 2 || r == 4) c->fused_rounds = (uint32_t)r;
   }
   if (const char *env = std::getenv("VKRHIP_TOP_LEVELS")) c->top_enabled = std::atoi(env) != 0;
+  if (const char *env = std::getenv("VKRHIP_STREAM_TILES")) c->stream_enabled = std::atoi(env) != 0;
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
     TRY(bind_device(c));
+    {
+      int cus = 0;
+      HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+      c->cu_count = cus > 0 ? (uint32_t)cus : 0u;
+    }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
@@ -1262,21 +1281,38 @@ static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *roun
   return tiles * (FUSED_ROUNDS / *rounds);
 }
 
-template <bool HAS_PARENT, bool TOP = false>
+// Large levels are walked by blocks that stream over several tiles: as many
+// blocks as the device holds at once (the kernel's waves-per-SIMD bound), tiles
+// beyond a block's first two handed out by a counter. Needs whole tiles per
+// block, few enough views for two sets of cull tables, and more tiles than one
+// resident set of blocks; returns the grid (0: a block per tile).
+template <bool HAS_PARENT>
+static unsigned stream_grid(vkrhip_ctx *c, FusedArgs &a, uint64_t tiles) {
+  const uint64_t resident = (uint64_t)c->cu_count * (HAS_PARENT ? 4u : 5u);
+  if (!c->stream_enabled || a.rounds != (uint32_t)FUSED_ROUNDS || a.c.views + 5u > 21u || !resident ||
+      tiles <= resident || tiles >= 0x7fffffffu || c->stream_used >= vkrhip_ctx::kStreamTickets)
+    return 0;
+  a.stream_tiles = (uint32_t)tiles;
+  a.stream_ticket = c->stream_tickets() + c->stream_used++;
+  return (unsigned)resident;
+}
+
+template <bool HAS_PARENT, bool TOP = false, bool STREAM = false>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
                                  bool bounds_out, bool first) {
   const dim3 g(grid), b(FUSED_BLOCK);
-  const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c) : cull_shared_bytes(a.c.views);
+  const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c)
+                         : cull_shared_bytes(a.c.views, STREAM ? 2u : 1u);
   if (ties) {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP, STREAM>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP, STREAM>, g, b, lds, a);
   } else {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP, STREAM>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM>, g, b, lds, a);
   }
 }
 
@@ -1310,10 +1346,19 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.t = transform_args(c, l);
     a.c = cull_args(c);
     a.seg_base = (uint32_t)seg_base;
-    if (l == 0 || !c->parent.p)
-      launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
-    else
-      launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
+    if (l == 0 || !c->parent.p) {
+      const unsigned streamed = stream_grid<false>(c, a, grid);
+      if (streamed)
+        launch_fused_variant<false, false, true>(c, a, streamed, ties, bounds_out, first);
+      else
+        launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
+    } else {
+      const unsigned streamed = stream_grid<true>(c, a, grid);
+      if (streamed)
+        launch_fused_variant<true, false, true>(c, a, streamed, ties, bounds_out, first);
+      else
+        launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
+    }
     first = false;
     seg_base += grid;
   }
@@ -1550,6 +1595,7 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
   }
   TRY(bind_device(c));
   c->frame_stages = stages;
+  c->stream_used = 0;
   const bool cull = (stages & VKRHIP_STAGE_CULL) != 0;
   const bool bounds_out = (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0;
   if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
