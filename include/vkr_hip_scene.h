@@ -191,6 +191,14 @@ int vkrhip_set_stream(vkrhip_ctx *ctx, void *hip_stream);
  * vkrhip_set_stream changed it), for callers that want to order their own work
  * (copies, collectives) with the context's. */
 void *vkrhip_get_stream(const vkrhip_ctx *ctx);
+/* On its own stream a context with a large hierarchy sorts and emits a frame's
+ * transparent rows on a second stream, beside the next frame's transform. Every
+ * entry point that reads, copies or hands out results orders the context's stream
+ * behind that work by itself; a caller that enqueues kernels of its own on
+ * vkrhip_get_stream() to read the transparent arrays calls vkrhip_join after
+ * vkrhip_frame first (one stream-wait, the host does not block). No counterpart in
+ * the reference, whose frame is one host thread. */
+int vkrhip_join(vkrhip_ctx *ctx);
 /* Waits for everything the context has enqueued (vkr_renderer_submit_packet
  * returns only after the payload was consumed, lib/src/renderer/vkr_render_packet.h:121-125). */
 int vkrhip_sync(vkrhip_ctx *ctx);

@@ -425,6 +425,55 @@ def test_merged_top_levels_on_and_off(oracle, monkeypatch, top_levels, dirty):
             world = want_world
 
 
+@pytest.mark.parametrize("overlap", ["0", "2"])
+@pytest.mark.parametrize("blend_fraction", [0.02, 0.6])
+def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_fraction):
+    """VKRHIP_OVERLAP_SORT=2: the transparent sort and emission of every frame run on
+    a second stream beside the next frame's transform (by default only large
+    hierarchies do that); =0 keeps them on the frame's stream. Frames are enqueued
+    in pairs with every node moved in between and nothing read, so the second
+    frame's transform overwrites the world matrices while the first frame's rows
+    may still be in flight; then a caller's kernel-side read is imitated with
+    join() + the device pointers. Small (rank kernel) and large (radix passes)
+    transparent counts."""
+    import torch
+    from vulkan_renderer_amd.parallel import wrap_device
+    synth = _synth()
+    monkeypatch.setenv("VKRHIP_OVERLAP_SORT", overlap)
+    sc = synth.deep_scene(260000, depth=5, seed=21, fanout=9, roots=11, blend_fraction=blend_fraction)
+    vs = synth.camera_views(cascades=2, far=900.0)
+    planes, required = view_set(vs)
+    with hip_scene_for(sc, 3) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, oracle_frame(oracle, sc, planes, required, vs.view, vs.projection), sc)
+        world = hs.read_world()
+        local = hs.read_locals()
+        flags = np.full(sc.n, DIRTY_WORLD, np.uint8)
+        out = hs.device_outputs()  # (the pointers stay as they are from frame to frame)
+        consumer = torch.cuda.ExternalStream(hs.stream_handle())
+        for pair in range(3):
+            for half in range(2):
+                local = local.copy()
+                local[:, 12] += np.float32(0.5 * (pair + 1) + 0.125 * half)
+                local[:, 14] -= np.float32(0.25 * (half + 1))
+                hs.upload_locals(local)
+                hs.upload_node_flags(flags)
+                hs.frame()
+                _, world, _, _ = oracle.scene_update(sc.parent, local=local, flags=flags, world=world)
+            ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, world=world)
+            if pair == 1:
+                # a consumer on the context's stream: join, then copy the device array there
+                hs.join()
+                t = int(ref["payload"]["counts"][3])
+                with torch.cuda.stream(consumer):
+                    keys = wrap_device(out.transparent_keys, t, torch.int64).clone()
+                consumer.synchronize()
+                assert (keys.cpu().numpy().view(np.uint64) == ref["payload"]["sort_keys"]).all()
+            compare_frame(hs, ref, sc, check_transform=False)
+            assert_bits_equal(hs.read_world(), world, f"world matrices, pair {pair}")
+
+
 @pytest.mark.parametrize("shape", ["flat", "deep"])
 def test_blocks_streaming_over_tiles(oracle, monkeypatch, shape):
     """VKRHIP_STREAM_TILES=1: levels with more tiles than the device holds blocks are

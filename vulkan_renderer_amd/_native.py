@@ -33,7 +33,7 @@ TIMER_NAMES = ["transform", "classify", "fused", "scan", "scatter", "sort", "emi
                "candidates", "frame"]
 
 EXPORTED_SYMBOLS = [
-    "vkrhip_create", "vkrhip_destroy", "vkrhip_last_error", "vkrhip_set_stream", "vkrhip_get_stream", "vkrhip_sync",
+    "vkrhip_create", "vkrhip_destroy", "vkrhip_last_error", "vkrhip_set_stream", "vkrhip_get_stream", "vkrhip_join", "vkrhip_sync",
     "vkrhip_set_hierarchy", "vkrhip_upload_trs", "vkrhip_upload_locals", "vkrhip_upload_worlds",
     "vkrhip_upload_node_flags", "vkrhip_mark_all", "vkrhip_set_candidates", "vkrhip_set_views",
     "vkrhip_frame", "vkrhip_get_frame_info", "vkrhip_get_device_outputs", "vkrhip_read_world",
@@ -229,6 +229,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_last_error.restype = C.c_char_p
     L.vkrhip_set_stream.argtypes = [vp, vp]
     L.vkrhip_get_stream.argtypes = [vp]
+    L.vkrhip_join.argtypes = [vp]
     L.vkrhip_get_stream.restype = vp
     L.vkrhip_sync.argtypes = [vp]
     L.vkrhip_set_hierarchy.argtypes = [vp, vp, u64, vp, u32]

@@ -815,7 +815,8 @@ struct GatherArgs {
   const uint32_t *remap;    // candidate -> packed row index when a publication is set, else null
   CompactionState *states;  // written by block 0
   uint32_t *visible;        // [view][visible_stride]
-  uint64_t *keys;           // compacted sort keys of the visible blend rows
+  uint64_t *keys;           // compact sort keys of the visible blend rows: depth bits << 32 | place
+  uint32_t *tsrc;           // the candidate of every visible blend row, by place
   uint64_t segments;
   uint64_t seg_stride;
   uint64_t visible_stride;
@@ -914,7 +915,10 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
       if (m == 0ull) continue;  // wave-uniform
       if ((m >> lane) & 1ull) {
         const uint64_t pos = p + (uint32_t)__popcll(m & lt_mask);
-        if (pos < a.transparent_capacity) a.keys[pos] = key[k];
+        if (pos < a.transparent_capacity) {
+          a.keys[pos] = (key[k] & 0xffffffff00000000ull) | pos;
+          a.tsrc[pos] = min(origin + k * 64u + lane, last_candidate);
+        }
       }
       p += (uint32_t)__popcll(m);
     }

@@ -425,11 +425,20 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
   }
 }
 
+// The keys that are sorted are "compact" keys: depth bits << 32 | the row's place
+// p among the frame's visible blend rows (candidate order, so the low word
+// orders ties like the source index does). Everything the emission needs of a
+// row was set aside under p when the frame's lists were gathered: its candidate
+// (tsrc) and its world matrix (tworld). The kernels here therefore read nothing
+// that the next frame's transform overwrites, and run beside it on a second
+// stream.
 struct EmitArgs {
-  const uint64_t *keys;      // sorted: ascending, or descending when keys_descending
+  const uint64_t *keys;      // sorted compact keys: ascending, or descending when keys_descending
   const uint32_t *counters;  // CNT_TRANSPARENT
-  const float4 *world;
-  const uint32_t *node;
+  const float4 *tworld;      // 4 x float4 per visible blend row
+  const uint32_t *tsrc;      // its candidate
+  const float4 *world;       // when tworld is null (single stream): the matrices are read in place,
+  const uint32_t *node;      //   through candidate -> node (null = identity)
   const uint4 *ident;  // 2 x uint4 per candidate
   uint4 *draws;        // 3 x uint4 per row: VkrDrawItem
   float4 *instances;   // 5 x float4 per row: VkrInstanceDataGPU
@@ -457,20 +466,28 @@ __host__ __device__ __forceinline__ uint32_t encode_scene_object_id(uint32_t ren
 // The part of piece `piece` that does not depend on the output row.
 __device__ __forceinline__ uint4 emit_piece_gather(const EmitArgs &a, uint64_t key,
                                                    uint32_t piece) {
-  // the low word is source_index + 1 (application.h:657-658)
-  const uint32_t i = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
+  const uint32_t p = (uint32_t)key;  // the row's place among the visible blend rows
+  if (piece >= 3u && piece < 7u) {
+    float4 c;
+    if (a.tworld) {
+      c = a.tworld[(uint64_t)p * 4u + (piece - 3u)];
+    } else {
+      const uint32_t i = a.tsrc[p];
+      const uint64_t nd = a.node ? a.node[i] : i;
+      c = a.world[nd * 4u + (piece - 3u)];
+    }
+    return make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z),
+                      __float_as_uint(c.w));
+  }
+  const uint32_t i = a.tsrc[p];
   if (piece == 0u) return a.ident[(uint64_t)i * 2u];  // mesh.id/.generation, geometry.id/.generation
   if (piece == 1u) {
     const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
     return make_uint4(id1.x, id1.y, id1.z, 1u);  // submesh_index, material, instance_count
   }
-  if (piece == 2u) return make_uint4(0u, 0u, (uint32_t)key, (uint32_t)(key >> 32));
-  if (piece < 7u) {
-    const uint64_t nd = a.node ? a.node[i] : i;
-    const float4 c = a.world[nd * 4u + (piece - 3u)];
-    return make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z),
-                      __float_as_uint(c.w));
-  }
+  // the sort key as the reference packs it: the low word is source_index + 1
+  // (application.h:573-587,657-658)
+  if (piece == 2u) return make_uint4(0u, 0u, (uint32_t)(a.index_base + i) + 1u, (uint32_t)(key >> 32));
   const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
   return make_uint4(encode_scene_object_id(id1.w), 0u, 0u, 0u);
 }
@@ -480,8 +497,8 @@ __device__ __forceinline__ void emit_piece_store(const EmitArgs &a, uint32_t row
   if (piece < 3u) {
     if (piece == 2u) {
       o.x = row;  // first_instance
-      a.out_keys[row] = key;
-      a.out_source[row] = (uint32_t)((uint64_t)((uint32_t)key - 1u) - a.index_base);
+      a.out_keys[row] = ((uint64_t)o.w << 32) | o.z;
+      a.out_source[row] = (uint32_t)((uint64_t)(o.z - 1u) - a.index_base);
     }
     a.draws[(uint64_t)row * 3u + piece] = o;
   } else {
@@ -494,6 +511,25 @@ __device__ __forceinline__ void emit_piece_store(const EmitArgs &a, uint32_t row
 __device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32_t row,
                                                        uint64_t key, uint32_t piece) {
   emit_piece_store(a, row, key, piece, emit_piece_gather(a, key, piece));
+}
+
+// The world matrices of the visible blend rows, set aside in row order (one
+// column per thread) so that the emission does not read world[] later.
+struct TransparentWorldArgs {
+  const uint32_t *counters;  // CNT_TRANSPARENT
+  const uint32_t *tsrc;
+  const uint32_t *node;  // candidate -> node, null = identity
+  const float4 *world;
+  float4 *tworld;
+};
+__global__ __launch_bounds__(256) void k_copy_transparent_world(TransparentWorldArgs a) {
+  const uint32_t count = a.counters[CNT_TRANSPARENT];
+  const uint32_t col = threadIdx.x & 3u;
+  for (uint32_t p = blockIdx.x * 64u + (threadIdx.x >> 2); p < count; p += gridDim.x * 64u) {
+    const uint32_t i = a.tsrc[p];
+    const uint64_t nd = a.node ? a.node[i] : i;
+    a.tworld[(uint64_t)p * 4u + col] = a.world[nd * 4u + col];
+  }
 }
 
 // Emission from the sorted key array: read backwards when it is ascending; when

@@ -214,6 +214,15 @@ struct vkrhip_ctx {
   void *comm = nullptr;  // ncclComm_t
   uint32_t comm_world = 1, comm_rank = 0;
   hipStream_t xstream = nullptr;
+  // Sort and emission of the transparent draws run on a stream of their own, beside
+  // the next frame's transform and cull (they read nothing those overwrite).
+  hipStream_t tstream = nullptr;
+  hipEvent_t ev_gathered = nullptr;  // main stream: the frame's keys and set-aside rows are complete
+  hipEvent_t ev_emitted = nullptr;   // side stream: the frame's draws are complete
+  bool side_pending = false;         // ev_emitted has not been waited for yet
+  int overlap_sort = 1;             // VKRHIP_OVERLAP_SORT: 0 one stream, 1 large hierarchies, 2 always
+  DevBuf<uint32_t> tsrc;
+  DevBuf<float4> tworld;
   hipEvent_t x_packed = nullptr;
   struct ExchangeSet {
     DevBuf<uint32_t> send, recv, merged_visible;
@@ -368,7 +377,9 @@ struct StageTimer {
   vkrhip_ctx *c;
   EventPair ev{};
   bool on = false;
-  StageTimer(vkrhip_ctx *ctx, int timer) : c(ctx) {
+  hipStream_t stream;
+  StageTimer(vkrhip_ctx *ctx, int timer, hipStream_t on_stream = nullptr)
+      : c(ctx), stream(on_stream ? on_stream : ctx->stream) {
     if (!(c->profiling & (1u << timer))) return;
     if (!c->free_events.empty()) {
       ev = c->free_events.back();
@@ -382,15 +393,25 @@ struct StageTimer {
     }
     ev.timer = timer;
     ev.samples = 1;
-    on = hipEventRecord(ev.start, c->stream) == hipSuccess;
+    on = hipEventRecord(ev.start, stream) == hipSuccess;
     if (!on) c->free_events.push_back(ev);
   }
   ~StageTimer() {
     if (!on) return;
-    (void)hipEventRecord(ev.stop, c->stream);
+    (void)hipEventRecord(ev.stop, stream);
     c->pending.push_back(ev);
   }
 };
+
+// Orders the main stream behind the side stream's last emission (a device-side
+// wait; the host does not block). Called wherever the main stream, or the host
+// through it, is about to read the draws or to change what the emission reads.
+int join_side(vkrhip_ctx *c) {
+  if (!c->side_pending) return VKRHIP_OK;
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_emitted, 0));
+  c->side_pending = false;
+  return VKRHIP_OK;
+}
 
 int drain_timers(vkrhip_ctx *c) {
   for (const EventPair &ev : c->pending) {
@@ -591,6 +612,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   }
   if (const char *env = std::getenv("VKRHIP_TOP_LEVELS")) c->top_enabled = std::atoi(env) != 0;
   if (const char *env = std::getenv("VKRHIP_STREAM_TILES")) c->stream_enabled = std::atoi(env) != 0;
+  if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
@@ -602,6 +624,9 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->tstream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
     const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
     TRY(dev_alloc(c, c->local, mn * 4));
     TRY(dev_alloc(c, c->world, mn * 4));
@@ -648,7 +673,15 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
 void vkrhip_destroy(vkrhip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->tstream) (void)hipStreamSynchronize(c->tstream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->tstream) (void)hipStreamDestroy(c->tstream);
+  if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+  if (c->ev_emitted) (void)hipEventDestroy(c->ev_emitted);
+  c->tstream = nullptr;
+  c->ev_gathered = c->ev_emitted = nullptr;
+  dev_free(c->tsrc);
+  dev_free(c->tworld);
   for (EventPair &ev : c->pending) {
     (void)hipEventDestroy(ev.start);
     (void)hipEventDestroy(ev.stop);
@@ -740,6 +773,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
 int vkrhip_set_stream(vkrhip_ctx *c, void *hip_stream) {
   if (!c) return VKRHIP_ERR_ARG;
   TRY(bind_device(c));
+  TRY(join_side(c));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return VKRHIP_OK;
@@ -747,9 +781,16 @@ int vkrhip_set_stream(vkrhip_ctx *c, void *hip_stream) {
 
 void *vkrhip_get_stream(const vkrhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+int vkrhip_join(vkrhip_ctx *c) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(bind_device(c));
+  return join_side(c);
+}
+
 int vkrhip_sync(vkrhip_ctx *c) {
   if (!c) return VKRHIP_ERR_ARG;
   TRY(bind_device(c));
+  TRY(join_side(c));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
 }
@@ -923,6 +964,10 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
     }
   }
   TRY(bind_device(c));
+  // the side stream may still emit the last frame's draws from the identity words
+  // and the key buffers that are replaced below
+  if (c->tstream) HIP_TRY(c, hipStreamSynchronize(c->tstream));
+  c->side_pending = false;
   uint64_t blend = 0;
   std::vector<uint32_t> transmissive;
   for (uint64_t i = 0; i < n; ++i) {
@@ -977,6 +1022,8 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
     TRY(dev_alloc(c, c->keys_b, tcap));
     TRY(dev_alloc(c, c->out_keys, tcap));
     TRY(dev_alloc(c, c->out_source, tcap));
+    TRY(dev_alloc(c, c->tsrc, tcap));
+    TRY(dev_alloc(c, c->tworld, tcap * 4));
     if (tcap >= (1ull << 30))
       return fail(c, VKRHIP_ERR_CAPACITY, "more than 2^30 sortable blend rows on one GPU");
     c->sort_tiles_stride = (uint32_t)ceil_div(tcap, SORT_TILE);
@@ -1451,6 +1498,7 @@ static int launch_compaction(vkrhip_ctx *c) {
     g.states = c->states.p;
     g.visible = c->visible.p;
     g.keys = c->keys_a.p;
+    g.tsrc = c->tsrc.p;
     g.segments = segments;
     g.seg_stride = c->seg_stride;
     g.visible_stride = c->visible_stride;
@@ -1466,10 +1514,15 @@ static int launch_compaction(vkrhip_ctx *c) {
   return VKRHIP_OK;
 }
 
-static EmitArgs emit_args(vkrhip_ctx *c) {
+// Hierarchies below this size keep the transparent sort on the frame's stream.
+constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
+
+static EmitArgs emit_args(vkrhip_ctx *c, bool set_aside) {
   EmitArgs e{};
   e.keys = c->keys_a.p;
   e.counters = c->counters();
+  e.tworld = set_aside ? c->tworld.p : nullptr;
+  e.tsrc = c->tsrc.p;
   e.world = c->world.p;
   e.node = c->node_identity ? nullptr : c->node.p;
   e.ident = c->ident.p;
@@ -1495,47 +1548,76 @@ static int launch_transparent(vkrhip_ctx *c) {
   const uint32_t hint = *reinterpret_cast<volatile uint32_t *>(c->host_hint);
   uint64_t expected = cap;
   if (hint != 0u) expected = std::min<uint64_t>(cap, (uint64_t)(hint - 1u) * 5u / 4u + 256u);
+  // On a second stream the sort and the emission run beside the next frame's
+  // transform. They must then read nothing that transform overwrites: the rows'
+  // world matrices are set aside first (main stream), everything else they read
+  // the frame's gather left for them. The two cross-stream waits cost about as
+  // much as a small frame takes, so small hierarchies stay on one stream, and so
+  // does a context with the multi-GPU exchange configured: its pack needs the
+  // sorted keys right behind the frame, which leaves nothing to overlap with.
+  // A caller's own stream (vkrhip_set_stream) carries all work of the context, as that call promises.
+  const bool overlap = c->x_world == 0 && c->stream == c->own_stream &&
+                       (c->overlap_sort >= 2 || (c->overlap_sort == 1 && c->n_nodes >= OVERLAP_MIN_NODES));
+  hipStream_t on = c->stream;
+  if (overlap) {
+    TransparentWorldArgs w{};
+    w.counters = c->counters();
+    w.tsrc = c->tsrc.p;
+    w.node = c->node_identity ? nullptr : c->node.p;
+    w.world = c->world.p;
+    w.tworld = c->tworld.p;
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(expected, 64), 1), 4096);
+    hipLaunchKernelGGL(k_copy_transparent_world, dim3(grid), dim3(256), 0, c->stream, w);
+    HIP_TRY(c, hipGetLastError());
+    on = c->tstream;
+    HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(on, c->ev_gathered, 0));
+  }
   if (expected <= RANK_LIMIT) {
-    StageTimer timer(c, VKRHIP_TIMER_SORT);
+    StageTimer timer(c, VKRHIP_TIMER_SORT, on);
     const unsigned grid = (unsigned)std::max<uint64_t>(1, ceil_div(expected, (uint64_t)RANK_BLOCK_KEYS));
-    hipLaunchKernelGGL(k_rank_emit, dim3(grid), dim3(SMALL_THREADS), 0, c->stream, emit_args(c),
-                       c->keys_a.p, c->keys_b.p);
+    hipLaunchKernelGGL(k_rank_emit, dim3(grid), dim3(SMALL_THREADS), 0, on, emit_args(c, overlap), c->keys_a.p,
+                       c->keys_b.p);
     HIP_TRY(c, hipGetLastError());
-    return VKRHIP_OK;
-  }
-  {
-    StageTimer timer(c, VKRHIP_TIMER_SORT);
-    // a block per expected tile, never more than the device holds at once (four
-    // 256-thread blocks per CU); tiles beyond the grid are handed out by ticket
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, SORT_TILE), 1024);
-    if (++c->sort_serial == 0u) c->sort_serial = 1u;
-    SortArgs s{};
-    s.state = c->sort_state();
-    s.status = c->sort_status.p;
-    s.counters = c->counters();
-    s.tiles_stride = c->sort_tiles_stride;
-    s.serial = c->sort_serial;
-    s.capacity = (uint32_t)c->tcap;
-    s.keys_in = c->keys_a.p;
-    hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-    bool in_a = true;
-    for (uint32_t pass = 0; pass < (uint32_t)SORT_PASSES; ++pass) {  // four passes end in keys_a again
-      s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
-      s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
-      s.pass = pass;
-      s.descending = pass + 1u == (uint32_t)SORT_PASSES;  // the draw order is back to front
-      hipLaunchKernelGGL(k_sort_pass, dim3(grid), dim3(SORT_BLOCK), 0, c->stream, s);
-      in_a = !in_a;
+  } else {
+    {
+      StageTimer timer(c, VKRHIP_TIMER_SORT, on);
+      // a block per expected tile, never more than the device holds at once (four
+      // 256-thread blocks per CU); tiles beyond the grid are handed out by ticket
+      const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, SORT_TILE), 1024);
+      if (++c->sort_serial == 0u) c->sort_serial = 1u;
+      SortArgs s{};
+      s.state = c->sort_state();
+      s.status = c->sort_status.p;
+      s.counters = c->counters();
+      s.tiles_stride = c->sort_tiles_stride;
+      s.serial = c->sort_serial;
+      s.capacity = (uint32_t)c->tcap;
+      s.keys_in = c->keys_a.p;
+      hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(SORT_BLOCK), 0, on, s);
+      bool in_a = true;
+      for (uint32_t pass = 0; pass < (uint32_t)SORT_PASSES; ++pass) {  // four passes end in keys_a again
+        s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
+        s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
+        s.pass = pass;
+        s.descending = pass + 1u == (uint32_t)SORT_PASSES;  // the draw order is back to front
+        hipLaunchKernelGGL(k_sort_pass, dim3(grid), dim3(SORT_BLOCK), 0, on, s);
+        in_a = !in_a;
+      }
+      HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipGetLastError());
+    {
+      StageTimer timer(c, VKRHIP_TIMER_EMIT, on);
+      const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, 32), 4096);
+      EmitArgs e = emit_args(c, overlap);
+      e.keys_descending = 1u;
+      hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, on, e);
+      HIP_TRY(c, hipGetLastError());
+    }
   }
-  {
-    StageTimer timer(c, VKRHIP_TIMER_EMIT);
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, 32), 4096);
-    EmitArgs e = emit_args(c);
-    e.keys_descending = 1u;
-    hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, c->stream, e);
-    HIP_TRY(c, hipGetLastError());
+  if (overlap) {
+    HIP_TRY(c, hipEventRecord(c->ev_emitted, on));
+    c->side_pending = true;
   }
   return VKRHIP_OK;
 }
@@ -1617,6 +1699,10 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
       if (stages & VKRHIP_STAGE_TRANSFORM) TRY(launch_transform(c));
       if (cull) TRY(launch_classify(c, bounds_out));
     }
+    // the previous frame's sort and emission (side stream) still own the other
+    // counter block, the key buffers and the set-aside rows: the scan zeroes that
+    // block and the gather refills the buffers
+    if (cull) TRY(join_side(c));
     if (cull) TRY(launch_compaction(c));
     if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c));
     if (stages & VKRHIP_STAGE_CANDIDATES) {
@@ -1640,6 +1726,7 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
   if (!c || !out) return VKRHIP_ERR_ARG;
   if (!c->frame_ran) return fail(c, VKRHIP_ERR_STATE, "no frame has run");
   TRY(bind_device(c));
+  TRY(join_side(c));  // (the sort's stall flag)
   static_assert(TF_STAT_SHARDS == STAT_SHARDS && TF_CNT_STRIDE == CNT_COUNT, "shard layout");
   std::vector<uint32_t> shards(CNT_COUNT * STAT_SHARDS);
   std::vector<uint64_t> tie_shards((size_t)VKRHIP_MAX_VIEWS * TIE_SHARDS);
@@ -1693,6 +1780,9 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
 
 int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   if (!c || !out) return VKRHIP_ERR_ARG;
+  // what the caller enqueues on the context's stream from here on is ordered behind
+  // the draws of the last frame, which a second stream wrote
+  if (bind_device(c) == VKRHIP_OK) (void)join_side(c);
   std::memset(out, 0, sizeof(*out));
   out->world = reinterpret_cast<const float *>(c->world.p);
   out->node_flags = c->flags();
@@ -1731,6 +1821,8 @@ static int ensure_pinned(vkrhip_ctx *c, void **p, size_t *have, size_t need) {
 int vkrhip_fill_world_payload(vkrhip_ctx *c, vkrhip_world_payload *out, vkrhip_visibility_stats *stats) {
   if (!c || !out) return VKRHIP_ERR_ARG;
   static_assert(sizeof(vkrhip_world_payload) == 88, "VkrWorldPassPayload is 88 bytes");
+  TRY(bind_device(c));
+  TRY(join_side(c));
   std::memset(out, 0, sizeof(*out));
   if (stats) std::memset(stats, 0, sizeof(*stats));
   if (c->n_cand > VKRHIP_DRAW_CANDIDATE_CAPACITY) {  // application.h:703-711
@@ -1786,6 +1878,7 @@ int vkrhip_fill_world_payload(vkrhip_ctx *c, vkrhip_world_payload *out, vkrhip_v
 static int read_back(vkrhip_ctx *c, void *dst, const void *src, size_t bytes) {
   if (bytes == 0) return VKRHIP_OK;
   TRY(bind_device(c));
+  TRY(join_side(c));
   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VKRHIP_OK;
@@ -2191,6 +2284,7 @@ int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, 
   if (c->published)
     return fail(c, VKRHIP_ERR_STATE,
                 "the exchange merges source-row indices; it cannot run while a publication is set");
+  TRY(join_side(c));  // the pack reads the frame's sorted keys
   ExchangePackArgs a{};
   a.states = c->states.p;
   a.visible = c->visible.p;

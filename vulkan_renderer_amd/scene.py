@@ -159,6 +159,11 @@ class HipScene:
         """hipStream_t the context enqueues on (its own stream by default)."""
         return int(self.lib.vkrhip_get_stream(self.ctx) or 0)
 
+    def join(self) -> None:
+        """Orders the context's stream behind the frame's transparent sort and
+        emission when they ran on the second stream (vkrhip_join)."""
+        self._ok(self.lib.vkrhip_join(self.ctx))
+
     def sync(self) -> None:
         self._ok(self.lib.vkrhip_sync(self.ctx))
 
