@@ -431,10 +431,10 @@ def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_f
     """VKRHIP_OVERLAP_SORT=2: the transparent sort and emission of every frame run on
     a second stream beside the next frame's transform (by default only large
     hierarchies do that); =0 keeps them on the frame's stream. Frames are enqueued
-    in pairs with every node moved in between and nothing read, so the second
-    frame's transform overwrites the world matrices while the first frame's rows
-    may still be in flight; then a caller's kernel-side read is imitated with
-    join() + the device pointers. Small (rank kernel) and large (radix passes)
+    in pairs with different dirty sets and nothing read in between, so the second
+    frame's transform overwrites world matrices while the first frame's rows may
+    still be in flight; then a caller's kernel-side read is imitated with join() +
+    the device pointers. Small (rank kernel) and large (radix passes)
     transparent counts."""
     import torch
     from vulkan_renderer_amd.parallel import wrap_device
@@ -449,18 +449,28 @@ def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_f
         compare_frame(hs, oracle_frame(oracle, sc, planes, required, vs.view, vs.projection), sc)
         world = hs.read_world()
         local = hs.read_locals()
-        flags = np.full(sc.n, DIRTY_WORLD, np.uint8)
         out = hs.device_outputs()  # (the pointers stay as they are from frame to frame)
         consumer = torch.cuda.ExternalStream(hs.stream_handle())
+        rng = np.random.default_rng(8)
         for pair in range(3):
             for half in range(2):
+                # the first frame of a pair moves every node, the second a few subtrees
+                # and leaves (a different dirty set: most world matrices stay as they are)
+                moved = np.arange(sc.n) if half == 0 else np.unique(np.concatenate(
+                    [rng.integers(0, 300, 6), rng.integers(0, sc.n, 500)]))
+                flags = np.zeros(sc.n, np.uint8)
+                flags[moved] = DIRTY_WORLD
                 local = local.copy()
-                local[:, 12] += np.float32(0.5 * (pair + 1) + 0.125 * half)
-                local[:, 14] -= np.float32(0.25 * (half + 1))
+                local[moved, 12] += np.float32(0.5 * (pair + 1) + 0.125 * half)
+                local[moved, 14] -= np.float32(0.25 * (half + 1))
                 hs.upload_locals(local)
                 hs.upload_node_flags(flags)
                 hs.frame()
                 _, world, _, _ = oracle.scene_update(sc.parent, local=local, flags=flags, world=world)
+                if pair == 2 and half == 0:
+                    # a frame without a cull in between (nothing moved): the frame after
+                    # it follows a frame that left nothing on the second stream
+                    hs.frame(STAGE_TRANSFORM)
             ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, world=world)
             if pair == 1:
                 # a consumer on the context's stream: join, then copy the device array there
