@@ -418,6 +418,11 @@ def main() -> int:
             "timed_stages": "transform + multi-view cull + compaction + transparent key sort and draw "
                             "emission, outputs left in HBM; the 144-byte candidate rows of "
                             "application_build_world_payload are NOT in it (see dropin)",
+            "streams": ("one (the multi-GPU exchange needs a frame's results right behind it)"
+                        if exchange is not None else
+                        "hierarchies of 4M nodes and more: the transparent sort and emission of a frame "
+                        "run on a second stream beside the next frame's transform (the dominant kernel's "
+                        "event time includes that contention); VKRHIP_OVERLAP_SORT=0 keeps one stream"),
             "exchange": ("one all-gather of packed blocks (visible lists + draw-key runs), "
                          "device-planned merge, overlapped with the next frame") if exchange is not None else "none",
         },
