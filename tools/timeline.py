@@ -1,14 +1,15 @@
 """Prints the kernel timeline (start, end, duration in us, queue, kernel) of the last
 frames in a rocprofv3 --kernel-trace CSV: python tools/timeline.py <csv> [frames]."""
 import csv
+import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "k_or_flags" in r["Kernel_Name"] or
-          ("k_propagate_classify" in r["Kernel_Name"] and "true, true, f" in r["Kernel_Name"])]
-# a frame starts with the merged top-level launch (the TOP template flag) or, flat scenes, any first fused launch
+# a frame starts with the merged top-level launch (the fifth template flag of the fused kernel)
+top = re.compile(r"k_propagate_classify<\w+, \w+, \w+, \w+, true")
+starts = [i for i, r in enumerate(rows) if top.search(r["Kernel_Name"])]
 first = starts[-(frames + 1)] if len(starts) > frames else 0
 t0 = int(rows[first]["Start_Timestamp"])
 for r in rows[first:]:

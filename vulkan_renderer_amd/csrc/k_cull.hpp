@@ -817,6 +817,9 @@ struct GatherArgs {
   uint32_t *visible;        // [view][visible_stride]
   uint64_t *keys;           // compact sort keys of the visible blend rows: depth bits << 32 | place
   uint32_t *tsrc;           // the candidate of every visible blend row, by place
+  const float4 *world;      // with tworld: the rows' world matrices are set aside by place
+  const uint32_t *node;     //   (candidate -> node, null = identity)
+  float4 *tworld;           // null: the emission reads world[] in place
   uint64_t segments;
   uint64_t seg_stride;
   uint64_t visible_stride;
@@ -868,7 +871,6 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seg)) *
                         seg_record_words(a.views);
   const uint32_t slot = lane & 15u, bucket = lane >> 4;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   // What the wave needs for four views, requested in one go: lane -> (view v0 +
   // lane / 16, slot lane % 16) for the masks; lane j < 16 -> row 4 v0 + j for the
@@ -896,31 +898,59 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
     return a.remap ? a.remap[min(candidate, last_candidate)] : (uint32_t)(a.index_base + candidate);
   };
 
-  // The visible blend rows, one lane per candidate, slot by slot: the sort keys
-  // of all sixteen slots are requested before the first one is stored.
+  // The visible blend rows, one lane per ROW: lane j takes the j-th set bit of the
+  // sixteen slot masks (candidate order, which is the order of the places), so
+  // that everything a row needs - its key and, when the sort runs on a second
+  // stream, its world matrix - is requested in one round for the whole segment.
   {
-    const unsigned long long blend = record[CULL_SLOTS * (a.views + 4u) + slot];  // lane k < 16: slot k
-    uint64_t p = a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg];
-    uint64_t key[CULL_SLOTS];
+    const unsigned long long blend =
+        lane < (uint32_t)CULL_SLOTS ? record[CULL_SLOTS * (a.views + 4u) + lane] : 0ull;  // lane k: slot k
+    const uint32_t in_slot = (uint32_t)__popcll(blend);
+    const uint32_t upto = wave_inclusive_scan(in_slot);  // lanes 0..15: rows of slots 0..k
+    const uint32_t rows = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+    const uint64_t first = a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg];
+    for (uint32_t j0 = 0; j0 < rows; j0 += 64u) {  // wave-uniform; one trip unless > 64 rows
+      const uint32_t j = j0 + lane;
+      // the slot of row j: how many slots end at or before it (their row counts ascend)
+      uint32_t k = 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)CULL_SLOTS; ++k) {
-      const unsigned long long m = readlane64(blend, k);
-      key[k] = 0ull;
-      if (m == 0ull) continue;  // wave-uniform
-      if ((m >> lane) & 1ull) key[k] = a.tkey[min(origin + k * 64u + lane, last_candidate)];
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)CULL_SLOTS; ++k) {
-      const unsigned long long m = readlane64(blend, k);
-      if (m == 0ull) continue;  // wave-uniform
-      if ((m >> lane) & 1ull) {
-        const uint64_t pos = p + (uint32_t)__popcll(m & lt_mask);
-        if (pos < a.transparent_capacity) {
-          a.keys[pos] = (key[k] & 0xffffffff00000000ull) | pos;
-          a.tsrc[pos] = min(origin + k * 64u + lane, last_candidate);
-        }
+      for (uint32_t step = (uint32_t)CULL_SLOTS / 2u; step != 0u; step >>= 1) {
+        const uint32_t ends = (uint32_t)__shfl((int)upto, (int)(k + step - 1u), 64);
+        if (ends <= j) k += step;
       }
-      p += (uint32_t)__popcll(m);
+      const unsigned long long m = shfl64(blend, k);
+      uint32_t r = j - (uint32_t)__shfl((int)(upto - in_slot), (int)k, 64);  // row j is the r-th set bit of m
+      // the r-th set bit, by halving
+      uint32_t w = (uint32_t)m, bit = 0u;
+      uint32_t c = (uint32_t)__popc(w);
+      if (r >= c) { r -= c; w = (uint32_t)(m >> 32); bit = 32u; }
+      c = (uint32_t)__popc(w & 0xffffu);
+      if (r >= c) { r -= c; w >>= 16; bit += 16u; }
+      c = (uint32_t)__popc(w & 0xffu);
+      if (r >= c) { r -= c; w >>= 8; bit += 8u; }
+      c = (uint32_t)__popc(w & 0xfu);
+      if (r >= c) { r -= c; w >>= 4; bit += 4u; }
+      c = (uint32_t)__popc(w & 0x3u);
+      if (r >= c) { r -= c; w >>= 2; bit += 2u; }
+      if (r >= (w & 1u)) bit += 1u;
+      const uint64_t pos = first + j;
+      if (j < rows && pos < a.transparent_capacity) {
+        const uint32_t candidate = min(origin + k * 64u + bit, last_candidate);
+        const uint64_t key = a.tkey[candidate];
+        if (a.tworld) {
+          const uint64_t nd = a.node ? a.node[candidate] : candidate;
+          // (named values, not an array: an array here is given LDS space addressed
+          // through the dispatch packet, a read of host memory in every wave)
+          const float4 c0 = a.world[nd * 4u], c1 = a.world[nd * 4u + 1u];
+          const float4 c2 = a.world[nd * 4u + 2u], c3 = a.world[nd * 4u + 3u];
+          a.tworld[pos * 4u] = c0;
+          a.tworld[pos * 4u + 1u] = c1;
+          a.tworld[pos * 4u + 2u] = c2;
+          a.tworld[pos * 4u + 3u] = c3;
+        }
+        a.keys[pos] = (key & 0xffffffff00000000ull) | pos;
+        a.tsrc[pos] = candidate;
+      }
     }
   }
 

@@ -513,25 +513,6 @@ __device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32
   emit_piece_store(a, row, key, piece, emit_piece_gather(a, key, piece));
 }
 
-// The world matrices of the visible blend rows, set aside in row order (one
-// column per thread) so that the emission does not read world[] later.
-struct TransparentWorldArgs {
-  const uint32_t *counters;  // CNT_TRANSPARENT
-  const uint32_t *tsrc;
-  const uint32_t *node;  // candidate -> node, null = identity
-  const float4 *world;
-  float4 *tworld;
-};
-__global__ __launch_bounds__(256) void k_copy_transparent_world(TransparentWorldArgs a) {
-  const uint32_t count = a.counters[CNT_TRANSPARENT];
-  const uint32_t col = threadIdx.x & 3u;
-  for (uint32_t p = blockIdx.x * 64u + (threadIdx.x >> 2); p < count; p += gridDim.x * 64u) {
-    const uint32_t i = a.tsrc[p];
-    const uint64_t nd = a.node ? a.node[i] : i;
-    a.tworld[(uint64_t)p * 4u + col] = a.world[nd * 4u + col];
-  }
-}
-
 // Emission from the sorted key array: read backwards when it is ascending; when
 // the last sort pass left it descending, a row's key does not depend on the
 // count and is requested together with it.

@@ -1462,7 +1462,7 @@ static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
   return VKRHIP_OK;
 }
 
-static int launch_compaction(vkrhip_ctx *c) {
+static int launch_compaction(vkrhip_ctx *c, bool set_aside) {
   const uint64_t segments = c->n_cand ? c->segments : 0;
   if (!segments) {  // nothing to compact: empty states, zero transparent rows (counters are zeroed)
     HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
@@ -1499,6 +1499,9 @@ static int launch_compaction(vkrhip_ctx *c) {
     g.visible = c->visible.p;
     g.keys = c->keys_a.p;
     g.tsrc = c->tsrc.p;
+    g.world = c->world.p;
+    g.node = c->node_identity ? nullptr : c->node.p;
+    g.tworld = set_aside ? c->tworld.p : nullptr;
     g.segments = segments;
     g.seg_stride = c->seg_stride;
     g.visible_stride = c->visible_stride;
@@ -1516,6 +1519,19 @@ static int launch_compaction(vkrhip_ctx *c) {
 
 // Hierarchies below this size keep the transparent sort on the frame's stream.
 constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
+
+// Whether the frame's transparent sort and emission go to the second stream,
+// beside the next frame's transform. They must then read nothing that transform
+// overwrites: the gather sets the rows' world matrices aside, everything else
+// they read the gather wrote for them anyway. The two cross-stream waits cost
+// about a quarter of a small frame, so small hierarchies stay on one stream; so
+// does a caller's own stream (vkrhip_set_stream promises all work on it) and a
+// context with the multi-GPU exchange configured (its pack needs the sorted keys
+// right behind the frame, which leaves nothing to overlap with).
+static bool sort_on_second_stream(const vkrhip_ctx *c) {
+  return c->x_world == 0 && c->stream == c->own_stream &&
+         (c->overlap_sort >= 2 || (c->overlap_sort == 1 && c->n_nodes >= OVERLAP_MIN_NODES));
+}
 
 static EmitArgs emit_args(vkrhip_ctx *c, bool set_aside) {
   EmitArgs e{};
@@ -1535,7 +1551,7 @@ static EmitArgs emit_args(vkrhip_ctx *c, bool set_aside) {
   return e;
 }
 
-static int launch_transparent(vkrhip_ctx *c) {
+static int launch_transparent(vkrhip_ctx *c, bool overlap) {
   const uint64_t cap = std::min<uint64_t>(c->tcap, std::max<uint64_t>(c->blend_rows, 1));
   // The element count is only known on the device; the host has the static bound
   // `cap` and the count the scan kernel reported for an earlier frame. When
@@ -1548,27 +1564,8 @@ static int launch_transparent(vkrhip_ctx *c) {
   const uint32_t hint = *reinterpret_cast<volatile uint32_t *>(c->host_hint);
   uint64_t expected = cap;
   if (hint != 0u) expected = std::min<uint64_t>(cap, (uint64_t)(hint - 1u) * 5u / 4u + 256u);
-  // On a second stream the sort and the emission run beside the next frame's
-  // transform. They must then read nothing that transform overwrites: the rows'
-  // world matrices are set aside first (main stream), everything else they read
-  // the frame's gather left for them. The two cross-stream waits cost about as
-  // much as a small frame takes, so small hierarchies stay on one stream, and so
-  // does a context with the multi-GPU exchange configured: its pack needs the
-  // sorted keys right behind the frame, which leaves nothing to overlap with.
-  // A caller's own stream (vkrhip_set_stream) carries all work of the context, as that call promises.
-  const bool overlap = c->x_world == 0 && c->stream == c->own_stream &&
-                       (c->overlap_sort >= 2 || (c->overlap_sort == 1 && c->n_nodes >= OVERLAP_MIN_NODES));
   hipStream_t on = c->stream;
   if (overlap) {
-    TransparentWorldArgs w{};
-    w.counters = c->counters();
-    w.tsrc = c->tsrc.p;
-    w.node = c->node_identity ? nullptr : c->node.p;
-    w.world = c->world.p;
-    w.tworld = c->tworld.p;
-    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(expected, 64), 1), 4096);
-    hipLaunchKernelGGL(k_copy_transparent_world, dim3(grid), dim3(256), 0, c->stream, w);
-    HIP_TRY(c, hipGetLastError());
     on = c->tstream;
     HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(on, c->ev_gathered, 0));
@@ -1703,8 +1700,9 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     // counter block, the key buffers and the set-aside rows: the scan zeroes that
     // block and the gather refills the buffers
     if (cull) TRY(join_side(c));
-    if (cull) TRY(launch_compaction(c));
-    if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c));
+    const bool overlap = (stages & VKRHIP_STAGE_TRANSPARENT) && sort_on_second_stream(c);
+    if (cull) TRY(launch_compaction(c, overlap));
+    if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c, overlap));
     if (stages & VKRHIP_STAGE_CANDIDATES) {
       TRY(launch_candidates(c));
       // the frame's totals, for vkrhip_fill_world_payload: summed on the device and
