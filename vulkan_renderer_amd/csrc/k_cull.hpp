@@ -586,15 +586,17 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
     Mat4 m;
     if (IDENTITY) {
       const uint64_t last4 = a.n * 4u - 1u;
-      float4 v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = a.world[min(base * 4u + t + 256u * (uint32_t)k, last4)];
+      // (named values: as an array the four loads are kept in scratch memory
+      // between the load and the LDS store)
+      const float4 v0 = a.world[min(base * 4u + t, last4)];
+      const float4 v1 = a.world[min(base * 4u + t + 256u, last4)];
+      const float4 v2 = a.world[min(base * 4u + t + 512u, last4)];
+      const float4 v3 = a.world[min(base * 4u + t + 768u, last4)];
       __syncthreads();  // the previous round's readers of s_mat are done
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t l = t + 256u * (uint32_t)k;
-        s_mat[(l >> 2) * MAT_LDS_STRIDE + (l & 3u)] = v[k];
-      }
+      s_mat[(t >> 2) * MAT_LDS_STRIDE + (t & 3u)] = v0;
+      s_mat[((t + 256u) >> 2) * MAT_LDS_STRIDE + (t & 3u)] = v1;
+      s_mat[((t + 512u) >> 2) * MAT_LDS_STRIDE + (t & 3u)] = v2;
+      s_mat[((t + 768u) >> 2) * MAT_LDS_STRIDE + (t & 3u)] = v3;
       __syncthreads();
       const float4 *p = s_mat + t * MAT_LDS_STRIDE;
       m.c[0] = p[0];
@@ -618,12 +620,21 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 1024;
 
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no
+// LDS round trips): four shifted adds scan each row of 16 lanes, then lane 15 of
+// rows 0 and 2 is added to rows 1 and 3, then lane 31 to rows 2 and 3. A lane
+// whose source lies outside its row, or whose row is masked, receives 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t u = __shfl_up(v, d, 64);
-    if ((int)lane_id() >= d) v += u;
-  }
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 

@@ -205,10 +205,15 @@ __global__ __launch_bounds__(256) void k_encode_visible(EncodeArgs a) {
   const uint64_t slot = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 1;
   const uint32_t half = threadIdx.x & 1u;
   if (slot >= st.visible_count) return;
-  uint32_t bucket = 0u;
+  // (the bucket's start is tracked beside the bucket: indexing the copied state
+  // with a run-time bucket would turn it into an array in memory)
+  uint32_t bucket = 0u, bucket_start = st.execution_ranges[0][0];
 #pragma unroll
   for (uint32_t b = 1; b < 4u; ++b)
-    if (st.execution_ranges[b][1] != 0u && slot >= st.execution_ranges[b][0]) bucket = b;
+    if (st.execution_ranges[b][1] != 0u && slot >= st.execution_ranges[b][0]) {
+      bucket = b;
+      bucket_start = st.execution_ranges[b][0];
+    }
   const uint32_t p = a.visible[(uint64_t)view * a.visible_stride + slot];
   const uint4 r0 = a.rows[(uint64_t)p * 3u];       // geometry, material, instance, first_index
   const uint4 r1 = a.rows[(uint64_t)p * 3u + 1u];  // index_count, vertex_offset, bucket, flags
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void k_encode_visible(EncodeArgs a) {
   } else {
     out[1] = make_uint4(r1.x, r1.y, bucket, r1.w);
     if (a.commands != nullptr) {
-      const uint32_t local = (uint32_t)slot - st.execution_ranges[bucket][0];
+      const uint32_t local = (uint32_t)slot - bucket_start;
       uint32_t *cmd = a.commands +
                       (((uint64_t)view * 4u + bucket) * a.partition_capacity + local) * 5u;
       cmd[0] = r1.x;  // index_count
