@@ -643,40 +643,77 @@ struct CandidateEmitArgs {
 };
 
 // application_emit_world_source, application.h:617-641: one 144-byte
-// VkrWorldDrawCandidate per source row, written as nine 16-byte pieces. Thread g
-// writes piece g of the output array as a whole (row g / 9, piece g % 9), so every
-// lane is busy and every wave store covers 1 KiB of consecutive bytes.
-__global__ __launch_bounds__(256) void k_emit_candidates(CandidateEmitArgs a) {
-  const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  const uint64_t out_row = g / 9u;
-  const uint32_t piece = (uint32_t)(g - out_row * 9u);
-  if (out_row >= a.n) return;
-  // the transmission stream repeats the rows of the transmissive sources
-  // (application.h:643-645)
-  const uint64_t row = a.list ? a.list[out_row] : out_row;
-  uint4 o;  // (each piece loads only what it is made of)
-  if (piece == 0u) {
-    o = a.ident[row * 2u];  // mesh, geometry
-  } else if (piece == 1u) {
-    const uint4 id1 = a.ident[row * 2u + 1u];
-    o = make_uint4(id1.x, id1.y, id1.z, 0u);  // submesh_index, material, pad
-  } else if (piece < 6u) {
-    const uint64_t nd = a.node ? a.node[row] : row;
-    const float4 c = a.world[nd * 4u + (piece - 2u)];
-    o = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z),
-                   __float_as_uint(c.w));
-  } else if (piece == 6u) {
-    const uint32_t render_id = reinterpret_cast<const uint32_t *>(a.ident)[row * 8u + 7u];
-    o = make_uint4(encode_scene_object_id(render_id), 0u, 0u, 0u);
-  } else if (piece == 7u) {
-    const float4 s = a.sphere[row];
-    o = make_uint4(__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.z),
-                   __float_as_uint(s.w));
-  } else {
-    const uint32_t cf = a.cflags[row];
-    o = make_uint4((cf >> CF_BUCKET_SHIFT) & 0xfu, cf & CF_REF_MASK, 0u, 0u);
+// VkrWorldDrawCandidate per source row, nine 16-byte pieces: 0 mesh + geometry,
+// 1 submesh / material, 2-5 the world matrix, 6 the object id, 7 the local
+// sphere, 8 bucket + flags. A block takes EMIT_ROWS consecutive output rows and
+// assembles them in LDS: every thread requests its eight 16-byte input pieces
+// (two of the identity words, four matrix columns, sphere, candidate word) at
+// once - consecutive lanes read consecutive pieces of each input array, so with
+// output row = source row = node every wave load covers 1 KiB of consecutive
+// bytes - and drops them where they belong in the rows; behind one barrier the
+// block copies the rows out as they lie, nine pieces per thread, every wave store
+// 1 KiB of consecutive bytes.
+constexpr uint32_t EMIT_ROWS = 256;
+constexpr uint32_t EMIT_PIECES = 9;
+
+__global__ __launch_bounds__(EMIT_ROWS) void k_emit_candidates(CandidateEmitArgs a) {
+  __shared__ uint4 s_rows[EMIT_ROWS * EMIT_PIECES];  // 36 KiB: four blocks per CU
+  const uint32_t t = threadIdx.x;
+  const uint64_t first = (uint64_t)blockIdx.x * EMIT_ROWS;  // < a.n (the grid is sized so)
+  const uint32_t rows_here = (uint32_t)min((uint64_t)EMIT_ROWS, a.n - first);
+  // Source row of the block's output row r (rows past the end repeat the last one
+  // and are not copied out); the transmission stream repeats the rows of the
+  // transmissive sources (application.h:643-645).
+  auto source = [&](uint32_t r) -> uint64_t {
+    const uint64_t out_row = first + min(r, rows_here - 1u);
+    return a.list ? (uint64_t)a.list[out_row] : out_row;
+  };
+  const uint64_t own = source(t);
+  uint4 id[2];
+  float4 col[4];
+#pragma unroll
+  for (uint32_t j = 0; j < 2u; ++j) {  // piece q & 1 of the identity words of row q >> 1
+    const uint32_t q = t + j * EMIT_ROWS;
+    id[j] = a.ident[source(q >> 1) * 2u + (q & 1u)];
   }
-  a.rows[out_row * 9u + piece] = o;
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; ++j) {  // column q & 3 of the matrix of row q >> 2
+    const uint32_t q = t + j * EMIT_ROWS;
+    const uint64_t row = source(q >> 2);
+    const uint64_t nd = a.node ? (uint64_t)a.node[row] : row;
+    col[j] = a.world[nd * 4u + (q & 3u)];
+  }
+  const float4 sph = a.sphere[own];
+  const uint32_t cf = a.cflags[own];
+#pragma unroll
+  for (uint32_t j = 0; j < 2u; ++j) {
+    const uint32_t q = t + j * EMIT_ROWS;
+    uint4 *row = s_rows + (q >> 1) * EMIT_PIECES;
+    if (q & 1u) {
+      row[1] = make_uint4(id[j].x, id[j].y, id[j].z, 0u);  // submesh_index, material, pad
+      row[6] = make_uint4(encode_scene_object_id(id[j].w), 0u, 0u, 0u);
+    } else {
+      row[0] = id[j];  // mesh, geometry
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; ++j) {
+    const uint32_t q = t + j * EMIT_ROWS;
+    s_rows[(q >> 2) * EMIT_PIECES + 2u + (q & 3u)] =
+        make_uint4(__float_as_uint(col[j].x), __float_as_uint(col[j].y), __float_as_uint(col[j].z),
+                   __float_as_uint(col[j].w));
+  }
+  s_rows[t * EMIT_PIECES + 7u] = make_uint4(__float_as_uint(sph.x), __float_as_uint(sph.y),
+                                            __float_as_uint(sph.z), __float_as_uint(sph.w));
+  s_rows[t * EMIT_PIECES + 8u] = make_uint4((cf >> CF_BUCKET_SHIFT) & 0xfu, cf & CF_REF_MASK, 0u, 0u);
+  __syncthreads();
+  uint4 *out = a.rows + first * EMIT_PIECES;
+  const uint32_t pieces_here = rows_here * EMIT_PIECES;
+#pragma unroll
+  for (uint32_t k = 0; k < EMIT_PIECES; ++k) {
+    const uint32_t i = t + k * EMIT_ROWS;
+    if (i < pieces_here) out[i] = s_rows[i];
+  }
 }
 
 }  // namespace vkr

@@ -1631,15 +1631,15 @@ static int launch_candidates(vkrhip_ctx *c) {
   a.cflags = c->cflags.p;
   a.rows = c->cand_rows.p;
   a.n = c->n_cand;
-  hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand * 9u, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand, EMIT_ROWS)), dim3(EMIT_ROWS), 0,
                      c->stream, a);
   if (c->n_transmission) {
     TRY(dev_alloc(c, c->transmission_rows, c->n_transmission * 9));
     a.rows = c->transmission_rows.p;
     a.n = c->n_transmission;
     a.list = c->transmission_list.p;
-    hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_transmission * 9u, 256)), dim3(256),
-                       0, c->stream, a);
+    hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_transmission, EMIT_ROWS)),
+                       dim3(EMIT_ROWS), 0, c->stream, a);
   }
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
