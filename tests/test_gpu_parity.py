@@ -425,6 +425,59 @@ def test_merged_top_levels_on_and_off(oracle, monkeypatch, top_levels, dirty):
             world = want_world
 
 
+@pytest.mark.parametrize("balance", ["1", "0"])
+def test_merged_top_levels_balanced(oracle, monkeypatch, balance):
+    """The merged launch sized for one resident set of blocks: the merged levels
+    here make more 256-node blocks than a 256-CU device holds at once, so the
+    widest of them gets longer blocks (two rounds of a tile each). Three frames,
+    every node moved and then a few subtrees, then a transform-only frame;
+    VKRHIP_TOP_BALANCE=0 is the plan with 256-node blocks throughout."""
+    synth = _synth()
+    monkeypatch.setenv("VKRHIP_TOP_BALANCE", balance)
+    sc = synth.deep_scene(1500000, depth=4, seed=18, fanout=200, roots=8, blend_fraction=0.05)
+    vs = synth.camera_views(cascades=2, far=700.0)
+    planes, required = view_set(vs)
+    rng = np.random.default_rng(4)
+    with hip_scene_for(sc, 3) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, oracle_frame(oracle, sc, planes, required, vs.view, vs.projection), sc)
+        world = hs.read_world()
+        local = hs.read_locals()
+        offsets = np.asarray(sc.level_offsets)
+        for frame in range(3):
+            if frame == 0:
+                flags = np.full(sc.n, DIRTY_WORLD, np.uint8)
+            else:  # a few nodes of every level, the end of the third level among them
+                flags = np.zeros(sc.n, np.uint8)
+                flags[rng.integers(0, int(offsets[2]), 4)] = DIRTY_WORLD
+                flags[rng.integers(int(offsets[3]) - 1500, int(offsets[3]), 30)] = DIRTY_WORLD
+                flags[rng.integers(0, sc.n, 60)] = DIRTY_WORLD
+            moved = np.flatnonzero(flags)
+            local = local.copy()
+            local[moved, 13] += np.float32(0.5 * (frame + 1))
+            hs.upload_locals(local)
+            hs.upload_node_flags(flags)
+            _, want_world, want_flags, dirty_list = oracle.scene_update(sc.parent, local=local, flags=flags,
+                                                                         world=world)
+            hs.frame()
+            ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, world=want_world)
+            compare_frame(hs, ref, sc, check_transform=False)
+            assert_bits_equal(hs.read_world(), want_world, f"world matrices, frame {frame}")
+            assert (hs.read_node_flags() == want_flags).all(), f"node flags, frame {frame}"
+            assert hs.frame_info().nodes_updated == dirty_list.shape[0] > 0
+            world = want_world
+        # transform only: the same plan without the cull
+        flags = np.full(sc.n, DIRTY_WORLD, np.uint8)
+        local = local.copy()
+        local[:, 12] -= np.float32(0.75)
+        hs.upload_locals(local)
+        hs.upload_node_flags(flags)
+        _, want_world, _, _ = oracle.scene_update(sc.parent, local=local, flags=flags, world=world)
+        hs.frame(STAGE_TRANSFORM)
+        assert_bits_equal(hs.read_world(), want_world, "world matrices, transform only")
+
+
 @pytest.mark.parametrize("overlap", ["0", "2"])
 @pytest.mark.parametrize("blend_fraction", [0.02, 0.6])
 def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_fraction):
@@ -482,28 +535,3 @@ def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_f
                 assert (keys.cpu().numpy().view(np.uint64) == ref["payload"]["sort_keys"]).all()
             compare_frame(hs, ref, sc, check_transform=False)
             assert_bits_equal(hs.read_world(), world, f"world matrices, pair {pair}")
-
-
-@pytest.mark.parametrize("shape", ["flat", "deep"])
-def test_blocks_streaming_over_tiles(oracle, monkeypatch, shape):
-    """VKRHIP_STREAM_TILES=1: levels with more tiles than the device holds blocks are
-    walked by resident blocks that take tile after tile (the pipeline runs across
-    tile boundaries, two sets of cull tables, tiles handed out by a counter).
-    Same results, two frames in a row."""
-    synth = _synth()
-    monkeypatch.setenv("VKRHIP_STREAM_TILES", "1")
-    if shape == "flat":
-        sc = synth.flat_scene(1400000 + 777, seed=5, blend_fraction=0.1)
-        vs = synth.camera_views(cascades=1)
-    else:
-        sc = synth.deep_scene(1700000, depth=3, seed=6, fanout=40, roots=30, blend_fraction=0.1)
-        vs = synth.camera_views(cascades=2, far=900.0)
-    planes, required = view_set(vs)
-    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
-    with hip_scene_for(sc, planes.shape[0]) as hs:
-        hs.set_views(planes, required, vs.view)
-        for _ in range(2):
-            hs.mark_all(DIRTY_WORLD)
-            hs.frame()
-            compare_frame(hs, ref, sc, check_transform=False)
-            assert_bits_equal(hs.read_world(), ref["world"], "world matrices")

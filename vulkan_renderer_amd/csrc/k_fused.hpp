@@ -67,11 +67,6 @@ struct FusedArgs {
   CullArgs c;         // c.n = candidates; candidate i <-> node i
   uint32_t rounds;    // rounds of a tile one block walks: 4, 2 or 1 (more, shorter blocks)
   uint32_t seg_base;  // cull segment of block 0 of this launch (segments follow launch order)
-  // A launch whose blocks stream over several tiles (0: a block per tile): the tiles
-  // of the level, and the counter that hands out the tiles beyond the first two of
-  // every block (zero when the launch starts).
-  uint32_t stream_tiles;
-  uint32_t *stream_ticket;
   // merged top levels only
   const TopDesc *top;
   const uint32_t *top_anc_node;
@@ -330,11 +325,9 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
     own_sgprs(a.c.seg_stride);
     own_sgprs(a.c.index_base);
   }
-  own_sgprs(a.stream_ticket);
 }
 
-template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
-          bool STREAM = false>
+template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false>
 // Four waves per SIMD below the root level: a level of 1M nodes is exactly one
 // resident set of blocks (4 per CU), and the register budget of 128 lets the
 // compiler keep the three pipeline stages apart. The root-level variant has no
@@ -346,9 +339,7 @@ k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ float4 s_par[HAS_PARENT && !TOP ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
   static_assert(!TOP || HAS_PARENT, "the merged top levels hold nodes with parents");
-  static_assert(!STREAM || (!TOP && CULL), "streaming is for the large levels of the fused path");
   __shared__ uint32_t s_updated;
-  __shared__ uint32_t s_ticket;  // streaming: the tile after the next one
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
   static_assert((F_DIRTY_LOCAL | F_DIRTY_WORLD | F_WORLD_UPDATED) < F_HAS_PARENT, "marker bit is free");
 
@@ -359,30 +350,12 @@ k_propagate_classify(FusedArgs a) {
   const uint32_t col = t & 3u;
   uint64_t tile_base;
   uint32_t lo, hi;  // the block's part of the level, as offsets into the tile
-  // Streaming (large levels): the block walks whole tiles of the level one after
-  // another - its own number, that plus the grid size, then whatever the ticket
-  // counter hands out - and the software pipeline runs across the tile
-  // boundaries, so only the block's first tile pays for a cold start.
-  // Only the next tile's number is carried; its span is worked out (scalar
-  // arithmetic) where it is used.
-  constexpr uint32_t NO_TILE = 0xffffffffu;
-  constexpr bool streaming = STREAM;
-  uint32_t nxt_tile = NO_TILE;  // tile of the level that follows the current one
-  auto level_tile = [&](uint32_t k, uint64_t &tb, uint32_t &l, uint32_t &h) {
-    tb = (a.t.begin / CULL_TILE + k) * CULL_TILE;
-    l = a.t.begin > tb ? (uint32_t)(a.t.begin - tb) : 0u;
-    h = (uint32_t)min((uint64_t)CULL_TILE, a.t.end - tb);
-    if (k == NO_TILE) l = h = 0u;  // no tile: no round of it is active
-  };
   TopDesc top{};
   if (TOP) {
     top = a.top[blockIdx.x];  // block-uniform: scalar loads
     tile_base = top.tile_base;
     lo = top.lo_hi & 0xffffu;
     hi = top.lo_hi >> 16;
-  } else if (streaming) {
-    level_tile(blockIdx.x, tile_base, lo, hi);
-    if (blockIdx.x + gridDim.x < a.stream_tiles) nxt_tile = blockIdx.x + gridDim.x;
   } else {
     // Small levels are cut into more blocks of fewer rounds: a lone block per CU
     // cannot hide its own load latency.
@@ -402,20 +375,11 @@ k_propagate_classify(FusedArgs a) {
   }
   if (t == 0) s_updated = 0u;
   CullShared s{};
-  if (CULL) s = cull_shared_init(a.c.views, streaming ? 2u : 1u);
-  uint32_t ticket = 0u;  // thread 0, streaming: the counter's answer, consumed when the tile ends
-  if (streaming && t == 0) ticket = atomicAdd(a.stream_ticket, 1u);
+  if (CULL) s = cull_shared_init(a.c.views);
 
-  // rounds that overlap the level (block-uniform); rounds 4-7 are rounds 0-3 of the next tile
+  // rounds that overlap the level (block-uniform)
   auto active = [&](int r) {
-    if (r < FUSED_ROUNDS)
-      return (uint32_t)r * FUSED_BLOCK < hi && (uint32_t)(r + 1) * FUSED_BLOCK > lo;
-    if (!streaming || r >= 2 * FUSED_ROUNDS) return false;
-    r -= FUSED_ROUNDS;
-    uint64_t tb;
-    uint32_t l, h;
-    level_tile(nxt_tile, tb, l, h);
-    return (uint32_t)r * FUSED_BLOCK < h && (uint32_t)(r + 1) * FUSED_BLOCK > l;
+    return r < FUSED_ROUNDS && (uint32_t)r * FUSED_BLOCK < hi && (uint32_t)(r + 1) * FUSED_BLOCK > lo;
   };
   // Three-deep software pipeline: while round r is computed, the matrices of
   // round r+1 and the head of round r+2 are in flight.
@@ -507,7 +471,6 @@ k_propagate_classify(FusedArgs a) {
     __syncthreads();  // LDS tables cleared
   }
 
-  for (uint32_t walked = 0;; ++walked) {  // one pass per tile (streaming), else exactly one
 #pragma unroll
   for (int round = 0; round < FUSED_ROUNDS; ++round) {
     const uint32_t rbase = (uint32_t)round * FUSED_BLOCK;
@@ -517,23 +480,13 @@ k_propagate_classify(FusedArgs a) {
     FusedParent par = par_next;
     head_next = head_after;
     if (active(round + 1)) {
-      // (round + 1 and round + 2 are constants here: which tile they fall in is known)
-      uint64_t tb = tile_base;
-      uint32_t l = lo, h = hi;
-      if (round + 1 >= FUSED_ROUNDS) level_tile(nxt_tile, tb, l, h);
-      const uint32_t rb = (uint32_t)((round + 1) % FUSED_ROUNDS) * FUSED_BLOCK;
-      fused_resolve_head(a, tb, l, h, rb, head_next);
+      fused_resolve_head(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
       // ahead of the matrices: loads return in issue order and the window is needed first
       if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
-      fused_issue_body<CULL>(a, tb, l, h, rb, head_next, body_next);
+      fused_issue_body<CULL>(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
-    if (active(round + 2)) {
-      uint64_t tb = tile_base;
-      uint32_t l = lo, h = hi;
-      if (round + 2 >= FUSED_ROUNDS) level_tile(nxt_tile, tb, l, h);
-      fused_issue_head<HAS_PARENT, CULL>(a, tb, l, h, (uint32_t)((round + 2) % FUSED_ROUNDS) * FUSED_BLOCK,
-                                         head_after);
-    }
+    if (active(round + 2))
+      fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, rbase + 2u * FUSED_BLOCK, head_after);
     if (!active(round)) continue;
 
     // ---- columns in: memory layout -> compute layout ----------------------------
@@ -651,20 +604,7 @@ k_propagate_classify(FusedArgs a) {
     classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, world,
                                          make_float4(hd.ls.x, hd.ls.y, hd.ls.z, hd.ls.w), cf);
   }
-  if (streaming && t == 0) s_ticket = 2u * gridDim.x + ticket;  // read behind the barrier below
-  if (CULL)
-    segment_finish<TIES>(a.c, s, streaming ? a.seg_base + (tile_base - a.t.begin / CULL_TILE * CULL_TILE) / CULL_TILE : seg,
-                         (uint32_t)tile_base);
-  if (!streaming || nxt_tile == NO_TILE) break;  // block-uniform
-  // the next tile becomes the current one; its first rounds are already in flight
-  level_tile(nxt_tile, tile_base, lo, hi);
-  nxt_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
-  if (nxt_tile >= a.stream_tiles) nxt_tile = NO_TILE;
-  if (t == 0) ticket = atomicAdd(a.stream_ticket, 1u);
-  // the other set of tables: its last readers finished before the barrier above
-  s = cull_shared_set(a.c.views, (walked + 1u) & 1u);
-  cull_clear_wave_slots(s);
-  }  // tiles
+  if (CULL) segment_finish<TIES>(a.c, s, seg, (uint32_t)tile_base);
   {
     const uint32_t wave_updates = wave_inclusive_scan(updated_here);
     if ((t & 63u) == 63u && wave_updates) atomicAdd(&s_updated, wave_updates);

@@ -79,6 +79,7 @@ struct vkrhip_ctx {
   DevBuf<TopDesc> top_desc;
   DevBuf<uint32_t> top_anc_node, top_anc_info;
   bool top_enabled = true;  // VKRHIP_TOP_LEVELS=0 switches the merged launch off (A/B runs)
+  bool top_balance = true;  // VKRHIP_TOP_BALANCE=0: 256-node blocks whatever their number
   uint32_t force_flags = 0;
   uint32_t fused_rounds = 0;  // tuning override (VKRHIP_FUSED_ROUNDS = 1, 2 or 4); 0 = by level size
   bool have_trs = false;
@@ -132,20 +133,8 @@ struct vkrhip_ctx {
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
   static constexpr size_t kSortStateBytes = sizeof(SortState);
   static constexpr size_t kCasterBoxBytes = sizeof(uint32_t) * 8;  // six keys, padded
-  static constexpr uint32_t kStreamTickets = 16;  // streaming launches of a frame (one counter each)
-  static constexpr size_t kStreamBytes = sizeof(uint32_t) * kStreamTickets;
-  static constexpr size_t kBlockBytes =
-      kCountersBytes + kTiesBytes + kSortStateBytes + kCasterBoxBytes + kStreamBytes;
-  uint32_t *stream_tickets() const {
-    return reinterpret_cast<uint32_t *>(counter_block(cur_block) + kCountersBytes + kTiesBytes +
-                                        kSortStateBytes + kCasterBoxBytes);
-  }
-  uint32_t stream_used = 0;   // counters handed out this frame
+  static constexpr size_t kBlockBytes = kCountersBytes + kTiesBytes + kSortStateBytes + kCasterBoxBytes;
   uint32_t cu_count = 0;
-  // VKRHIP_STREAM_TILES=1: large levels are walked by resident blocks that stream over
-  // several tiles. Off by default: the state a block carries from tile to tile costs
-  // the kernel registers it does not have (scratch traffic), and it runs slower.
-  bool stream_enabled = false;
   uint32_t *caster_box() const {
     return reinterpret_cast<uint32_t *>(counter_block(cur_block) + kCountersBytes + kTiesBytes + kSortStateBytes);
   }
@@ -490,7 +479,9 @@ struct TopPlanHost {
   std::vector<uint32_t> anc_node, anc_info;
 };
 
-TopPlanHost build_top_plan(const uint32_t *parent, const std::vector<uint64_t> &lo, uint32_t levels) {
+// `resident`: blocks of the merged launch the device holds at once (0: unknown).
+TopPlanHost build_top_plan(const uint32_t *parent, const std::vector<uint64_t> &lo, uint32_t levels,
+                           uint64_t resident) {
   TopPlanHost plan;
   if (!parent || levels < 2) return plan;
   // how many levels fit the tile budget
@@ -507,71 +498,92 @@ TopPlanHost build_top_plan(const uint32_t *parent, const std::vector<uint64_t> &
   struct Range {
     uint32_t first, count;
   };
+  // One block: nodes [nb, ne) of one level, inside one tile. False: the hierarchy
+  // does not fit the scheme (the caller drops what it was building).
+  auto add_block = [&](uint64_t nb, uint64_t ne) -> bool {
+    const uint64_t tile_base = nb / CULL_TILE * CULL_TILE;
+    // ranges of ancestors, nearest level first
+    std::vector<Range> chain;
+    uint64_t rb = nb, re = ne;
+    for (;;) {
+      uint32_t pmin = VKRHIP_NO_PARENT, pmax = 0;
+      for (uint64_t i = rb; i < re; ++i) {
+        const uint32_t p = parent[i];
+        if (p == VKRHIP_NO_PARENT) continue;
+        pmin = std::min(pmin, p);
+        pmax = std::max(pmax, p);
+      }
+      if (pmin == VKRHIP_NO_PARENT) break;  // only roots left
+      // a range must stay inside one level, above the level it was derived from:
+      // its nodes are recomputed side by side in one step of the chain
+      const size_t lvl = (size_t)(std::upper_bound(lo.begin(), lo.end(), (uint64_t)pmin) - lo.begin()) - 1u;
+      if ((uint64_t)pmax >= lo[lvl + 1] || lo[lvl + 1] > rb) return false;
+      chain.push_back({pmin, pmax - pmin + 1u});
+      if (chain.size() > kTopMaxSteps) return false;
+      rb = pmin;
+      re = (uint64_t)pmax + 1u;
+    }
+    uint64_t total = 0;
+    for (const Range &r : chain) total += r.count;
+    if (total > kTopMaxAncestors) return false;
+    TopDesc d{};
+    d.tile_base = (uint32_t)tile_base;
+    d.lo_hi = (uint32_t)(nb - tile_base) | ((uint32_t)(ne - tile_base) << 16);
+    d.anc_off = (uint32_t)plan.anc_node.size();
+    d.anc_count = (uint32_t)total;
+    d.steps = (uint32_t)chain.size();
+    // root side first: step s holds chain[steps - 1 - s]
+    std::vector<uint32_t> slot_base(chain.size());
+    uint32_t slot = 0;
+    for (size_t s2 = 0; s2 < chain.size(); ++s2) {
+      slot_base[chain.size() - 1 - s2] = slot;
+      slot += chain[chain.size() - 1 - s2].count;
+    }
+    for (size_t s2 = 0; s2 < chain.size(); ++s2) {
+      const size_t ci = chain.size() - 1 - s2;  // index into chain (0 = the parents' level)
+      const Range &r = chain[ci];
+      for (uint32_t j = 0; j < r.count; ++j) {
+        const uint32_t g = r.first + j;
+        const uint32_t p = parent[g];
+        uint32_t pslot = 0xffffu;
+        if (p != VKRHIP_NO_PARENT) pslot = slot_base[ci + 1] + (p - chain[ci + 1].first);
+        plan.anc_node.push_back(g);
+        plan.anc_info.push_back(pslot | ((uint32_t)s2 << 16));
+      }
+    }
+    if (!chain.empty()) {
+      d.par_first = chain[0].first;
+      d.par_slot = slot_base[0];
+    }
+    plan.anc_cap = std::max(plan.anc_cap, (uint32_t)total);
+    plan.desc.push_back(d);
+    return true;
+  };
+  // Nodes per block. The levels are small, so many short blocks hide one
+  // another's load latency better than a few long ones: a block per ROUND of a
+  // tile (256 nodes) - unless that makes more blocks than the device holds at
+  // once, where a second wave of blocks would cost a second chain of dependent
+  // loads: then the levels with the most blocks get longer ones.
+  std::vector<uint32_t> span(k, FUSED_BLOCK);
+  auto level_blocks = [&](uint32_t l) -> uint64_t {
+    return lo[l + 1] > lo[l] ? ceil_div(lo[l + 1], span[l]) - lo[l] / span[l] : 0u;
+  };
+  while (resident) {
+    uint64_t total = 0;
+    uint32_t widest = k;
+    for (uint32_t l = 0; l < k; ++l) {
+      total += level_blocks(l);
+      if (span[l] < (uint32_t)CULL_TILE && (widest == k || level_blocks(l) > level_blocks(widest))) widest = l;
+    }
+    if (total <= resident || widest == k) break;
+    span[widest] *= 2u;
+  }
   for (uint32_t l = 0; l < k; ++l) {
     const uint64_t b = lo[l], e = lo[l + 1];
     if (e == b) continue;
-    // a block per ROUND of a tile (256 nodes): the levels are small, so many short
-    // blocks hide one another's load latency better than a few long ones
-    for (uint64_t chunk = b / FUSED_BLOCK; chunk < ceil_div(e, FUSED_BLOCK); ++chunk) {
-      const uint64_t tile_base = chunk * FUSED_BLOCK / CULL_TILE * CULL_TILE;
-      const uint64_t nb = std::max<uint64_t>(b, chunk * FUSED_BLOCK);
-      const uint64_t ne = std::min<uint64_t>(e, (chunk + 1) * FUSED_BLOCK);
-      // ranges of ancestors, nearest level first
-      std::vector<Range> chain;
-      uint64_t rb = nb, re = ne;
-      for (;;) {
-        uint32_t pmin = VKRHIP_NO_PARENT, pmax = 0;
-        for (uint64_t i = rb; i < re; ++i) {
-          const uint32_t p = parent[i];
-          if (p == VKRHIP_NO_PARENT) continue;
-          pmin = std::min(pmin, p);
-          pmax = std::max(pmax, p);
-        }
-        if (pmin == VKRHIP_NO_PARENT) break;  // only roots left
-        // a range must stay inside one level, above the level it was derived from:
-        // its nodes are recomputed side by side in one step of the chain
-        const size_t lvl = (size_t)(std::upper_bound(lo.begin(), lo.end(), (uint64_t)pmin) - lo.begin()) - 1u;
-        if ((uint64_t)pmax >= lo[lvl + 1] || lo[lvl + 1] > rb) return TopPlanHost();
-        chain.push_back({pmin, pmax - pmin + 1u});
-        if (chain.size() > kTopMaxSteps) return TopPlanHost();
-        rb = pmin;
-        re = (uint64_t)pmax + 1u;
-      }
-      uint64_t total = 0;
-      for (const Range &r : chain) total += r.count;
-      if (total > kTopMaxAncestors) return TopPlanHost();
-      TopDesc d{};
-      d.tile_base = (uint32_t)tile_base;
-      d.lo_hi = (uint32_t)(nb - tile_base) | ((uint32_t)(ne - tile_base) << 16);
-      d.anc_off = (uint32_t)plan.anc_node.size();
-      d.anc_count = (uint32_t)total;
-      d.steps = (uint32_t)chain.size();
-      // root side first: step s holds chain[steps - 1 - s]
-      std::vector<uint32_t> slot_base(chain.size());
-      uint32_t slot = 0;
-      for (size_t s2 = 0; s2 < chain.size(); ++s2) {
-        slot_base[chain.size() - 1 - s2] = slot;
-        slot += chain[chain.size() - 1 - s2].count;
-      }
-      for (size_t s2 = 0; s2 < chain.size(); ++s2) {
-        const size_t ci = chain.size() - 1 - s2;  // index into chain (0 = the parents' level)
-        const Range &r = chain[ci];
-        for (uint32_t j = 0; j < r.count; ++j) {
-          const uint32_t g = r.first + j;
-          const uint32_t p = parent[g];
-          uint32_t pslot = 0xffffu;
-          if (p != VKRHIP_NO_PARENT) pslot = slot_base[ci + 1] + (p - chain[ci + 1].first);
-          plan.anc_node.push_back(g);
-          plan.anc_info.push_back(pslot | ((uint32_t)s2 << 16));
-        }
-      }
-      if (!chain.empty()) {
-        d.par_first = chain[0].first;
-        d.par_slot = slot_base[0];
-      }
-      plan.anc_cap = std::max(plan.anc_cap, (uint32_t)total);
-      plan.desc.push_back(d);
-    }
+    for (uint64_t chunk = b / span[l]; chunk < ceil_div(e, span[l]); ++chunk)
+      if (!add_block(std::max<uint64_t>(b, chunk * span[l]), std::min<uint64_t>(e, (chunk + 1) * span[l])))
+        return TopPlanHost();
   }
   plan.levels = k;
   plan.anc_cap = (plan.anc_cap + 63u) & ~63u;
@@ -611,7 +623,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     if (r == 1 || r == 2 || r == 4) c->fused_rounds = (uint32_t)r;
   }
   if (const char *env = std::getenv("VKRHIP_TOP_LEVELS")) c->top_enabled = std::atoi(env) != 0;
-  if (const char *env = std::getenv("VKRHIP_STREAM_TILES")) c->stream_enabled = std::atoi(env) != 0;
+  if (const char *env = std::getenv("VKRHIP_TOP_BALANCE")) c->top_balance = std::atoi(env) != 0;
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
@@ -840,7 +852,8 @@ int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes
   c->top_levels = 0;
   c->top_blocks = 0;
   if (c->top_enabled && n_nodes) {
-    const TopPlanHost plan = build_top_plan(parent, lo, levels);
+    const TopPlanHost plan =
+        build_top_plan(parent, lo, levels, c->top_balance ? (uint64_t)c->cu_count * 4u : 0u);
     if (plan.levels) {
       TRY(dev_alloc(c, c->top_desc, plan.desc.size()));
       TRY(dev_alloc(c, c->top_anc_node, std::max<size_t>(plan.anc_node.size(), 1)));
@@ -1328,38 +1341,22 @@ static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *roun
   return tiles * (FUSED_ROUNDS / *rounds);
 }
 
-// Large levels are walked by blocks that stream over several tiles: as many
-// blocks as the device holds at once (the kernel's waves-per-SIMD bound), tiles
-// beyond a block's first two handed out by a counter. Needs whole tiles per
-// block, few enough views for two sets of cull tables, and more tiles than one
-// resident set of blocks; returns the grid (0: a block per tile).
-template <bool HAS_PARENT>
-static unsigned stream_grid(vkrhip_ctx *c, FusedArgs &a, uint64_t tiles) {
-  const uint64_t resident = (uint64_t)c->cu_count * (HAS_PARENT ? 4u : 5u);
-  if (!c->stream_enabled || a.rounds != (uint32_t)FUSED_ROUNDS || a.c.views + 5u > 21u || !resident ||
-      tiles <= resident || tiles >= 0x7fffffffu || c->stream_used >= vkrhip_ctx::kStreamTickets)
-    return 0;
-  a.stream_tiles = (uint32_t)tiles;
-  a.stream_ticket = c->stream_tickets() + c->stream_used++;
-  return (unsigned)resident;
-}
-
-template <bool HAS_PARENT, bool TOP = false, bool STREAM = false>
+template <bool HAS_PARENT, bool TOP = false>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
                                  bool bounds_out, bool first) {
   const dim3 g(grid), b(FUSED_BLOCK);
   const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c)
-                         : cull_shared_bytes(a.c.views, STREAM ? 2u : 1u);
+                         : cull_shared_bytes(a.c.views);
   if (ties) {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP, STREAM>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP, STREAM>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP>, g, b, lds, a);
   } else {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP, STREAM>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP>, g, b, lds, a);
   }
 }
 
@@ -1394,17 +1391,9 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.c = cull_args(c);
     a.seg_base = (uint32_t)seg_base;
     if (l == 0 || !c->parent.p) {
-      const unsigned streamed = stream_grid<false>(c, a, grid);
-      if (streamed)
-        launch_fused_variant<false, false, true>(c, a, streamed, ties, bounds_out, first);
-      else
-        launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
+      launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
     } else {
-      const unsigned streamed = stream_grid<true>(c, a, grid);
-      if (streamed)
-        launch_fused_variant<true, false, true>(c, a, streamed, ties, bounds_out, first);
-      else
-        launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
+      launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
     }
     first = false;
     seg_base += grid;
@@ -1674,7 +1663,6 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
   }
   TRY(bind_device(c));
   c->frame_stages = stages;
-  c->stream_used = 0;
   const bool cull = (stages & VKRHIP_STAGE_CULL) != 0;
   const bool bounds_out = (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0;
   if (bounds_out) TRY(dev_alloc(c, c->world_bounds, std::max<uint64_t>(c->cfg.max_candidates, 1)));
