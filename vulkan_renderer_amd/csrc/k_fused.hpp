@@ -224,6 +224,17 @@ struct FusedParent {
   bool ok;        // wave-uniform
 };
 
+// Largest value of the wave (a scalar), by the moves of wave_inclusive_scan.
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+  v = max(v, dpp_or_zero<0x111, 0xf>(v));  // row_shr:1
+  v = max(v, dpp_or_zero<0x112, 0xf>(v));  // row_shr:2
+  v = max(v, dpp_or_zero<0x114, 0xf>(v));  // row_shr:4
+  v = max(v, dpp_or_zero<0x118, 0xf>(v));  // row_shr:8
+  v = max(v, dpp_or_zero<0x142, 0xa>(v));  // row_bcast:15 into rows 1 and 3
+  v = max(v, dpp_or_zero<0x143, 0xc>(v));  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Needs a resolved head (h.p is NO_PARENT for roots and outside the level).
 __device__ __forceinline__ void fused_issue_parent(const FusedArgs &a, const FusedHead &h,
                                                    FusedParent &par) {
@@ -236,8 +247,11 @@ __device__ __forceinline__ void fused_issue_parent(const FusedArgs &a, const Fus
   par.pmin = have ? p0 : 0u;
   const unsigned long long inside = __ballot(h.p - par.pmin < 16u);
   par.ok = (inside | ~have) == ~0ull;
-  // parents sit before the level, so the window is cut there (and stays inside the arrays)
-  const uint32_t last = a.t.begin ? (uint32_t)a.t.begin - 1u : 0u;
+  // The window is cut behind the wave's last parent (it also stays inside the
+  // arrays that way): the lanes beyond it repeat that parent's columns, which
+  // costs no memory traffic - with a fan-out of 8 the wave's 64 nodes hang from 8
+  // or 9 parents, and a full window of 16 would fetch twice what is needed.
+  const uint32_t last = wave_max(h.p != NO_PARENT ? h.p : 0u);
   const uint32_t lane = threadIdx.x & 63u;
   par.pm = a.t.world[(uint64_t)min(par.pmin + (lane >> 2), last) * 4u + (lane & 3u)];
   par.pf = a.t.flags_out[min(par.pmin + (lane & 15u), last)];  // as the parents' launch left them
