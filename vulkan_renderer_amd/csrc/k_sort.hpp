@@ -707,12 +707,15 @@ __global__ __launch_bounds__(EMIT_ROWS) void k_emit_candidates(CandidateEmitArgs
                                             __float_as_uint(sph.z), __float_as_uint(sph.w));
   s_rows[t * EMIT_PIECES + 8u] = make_uint4((cf >> CF_BUCKET_SHIFT) & 0xfu, cf & CF_REF_MASK, 0u, 0u);
   __syncthreads();
-  uint4 *out = a.rows + first * EMIT_PIECES;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 *out4 = reinterpret_cast<u32x4 *>(a.rows + first * EMIT_PIECES);
+  const u32x4 *s_rows4 = reinterpret_cast<const u32x4 *>(s_rows);
   const uint32_t pieces_here = rows_here * EMIT_PIECES;
 #pragma unroll
   for (uint32_t k = 0; k < EMIT_PIECES; ++k) {
     const uint32_t i = t + k * EMIT_ROWS;
-    if (i < pieces_here) out[i] = s_rows[i];
+    // (streaming stores: nothing on the device reads the rows back)
+    if (i < pieces_here) __builtin_nontemporal_store(s_rows4[i], out4 + i);
   }
 }
 
