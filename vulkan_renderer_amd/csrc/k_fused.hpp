@@ -282,7 +282,8 @@ __device__ __forceinline__ void store_matrices(float4 *s_mat, float4 *dst, uint6
   for (int r = 0; r < 4; ++r) {
     const float4 v = in0[r * 16 * MAT_LDS_STRIDE];
     const uint32_t chunk = (uint32_t)(want >> (16 * r)) & 0xffffu;  // scalar
-    if ((chunk >> lane_bit) & 1u) out0[r * 16 * 4] = v;
+    if ((chunk >> lane_bit) & 1u)
+      __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(out0 + r * 16 * 4));
   }
   __builtin_amdgcn_wave_barrier();
 }
