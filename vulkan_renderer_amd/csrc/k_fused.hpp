@@ -100,6 +100,22 @@ __device__ __forceinline__ T *at32(T *uniform_base, uint32_t index) {
   return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
 }
 
+// STREAM: a frame whose arrays do not fit the last-level cache (256 MB) reads
+// every input once and writes every output once, so keeping any of it in a
+// cache only evicts what IS read twice (the parents' matrices); such frames
+// mark their loads and stores as streaming. A scene that fits the cache is found
+// there by the next frame and must not use the hint (1M nodes: 30 -> 32.5 us).
+template <bool STREAM, typename T>
+__device__ __forceinline__ T load_once(const T *p) {
+  if constexpr (STREAM) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool STREAM, typename T>
+__device__ __forceinline__ void store_once(T *p, T v) {
+  if constexpr (STREAM) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // What one thread loads for one round, in two dependent steps: the head (flags,
 // parent index, cull inputs of its own node) depends on nothing; the matrix
 // columns are picked by the flags of the head. Both steps are unconditional
@@ -126,22 +142,22 @@ __device__ __forceinline__ uint32_t in_range_mask(uint32_t rel, uint32_t lo, uin
   return (rel >= lo && rel < hi) ? 0xffffffffu : 0u;
 }
 
-template <bool HAS_PARENT, bool CULL>
+template <bool HAS_PARENT, bool CULL, bool STREAM>
 __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h) {
   const uint32_t rel = clamp_rel(rbase + threadIdx.x, lo, hi);  // < 1024: every offset fits 32 bits
-  h.f = *at32(a.t.flags_in + tile_base, rel);
+  h.f = load_once<STREAM>(at32(a.t.flags_in + tile_base, rel));
   h.p = NO_PARENT;
-  if (HAS_PARENT) h.p = *at32(a.t.parent + tile_base, rel);
+  if (HAS_PARENT) h.p = load_once<STREAM>(at32(a.t.parent + tile_base, rel));
   h.ls = f32x4{0.f, 0.f, 0.f, 0.f};
   h.cf = 0u;
   if (CULL) {
     // (candidate i <-> node i; the tile's first node is a candidate, or the block has none to classify)
     const uint64_t cbase = min(tile_base, a.c.n - 1u);
     const uint32_t crel = (uint32_t)min((uint64_t)rel, a.c.n - 1u - cbase);
-    h.ls = *at32(reinterpret_cast<const f32x4 *>(a.c.sphere) + cbase, crel);
-    h.cf = *at32(a.c.cflags + cbase, crel);
+    h.ls = load_once<STREAM>(at32(reinterpret_cast<const f32x4 *>(a.c.sphere) + cbase, crel));
+    h.cf = load_once<STREAM>(at32(a.c.cflags + cbase, crel));
   }
 }
 
@@ -177,7 +193,7 @@ struct FusedBody {
 // rotation and scale, from which the local matrix is rebuilt when the round is
 // computed. The column lanes learn the flags of the node they fetch for from
 // the lane that owns it (a wave shuffle). One unconditional load per step.
-template <int R>
+template <int R, bool STREAM>
 __device__ __forceinline__ void fused_issue_column(const FusedArgs &a, uint64_t tile_base,
                                                    uint32_t lo, uint32_t hi, uint32_t rbase,
                                                    const FusedHead &h, FusedBody &b) {
@@ -190,17 +206,17 @@ __device__ __forceinline__ void fused_issue_column(const FusedArgs &a, uint64_t 
   const bool hl = (f & (F_DIRTY_LOCAL | F_DIRTY_WORLD)) != 0;
   const bool rebuilt = have_trs && (f & F_DIRTY_LOCAL) != 0;
   const float4 *src = rebuilt ? piece + node : (hl ? a.t.local : a.t.world) + node * 4u + col;
-  b.at<R>() = *reinterpret_cast<const f32x4 *>(src);
+  b.at<R>() = load_once<STREAM>(reinterpret_cast<const f32x4 *>(src));
 }
 
-template <bool CULL>
+template <bool CULL, bool STREAM>
 __device__ __forceinline__ void fused_issue_body(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h, FusedBody &b) {
-  fused_issue_column<0>(a, tile_base, lo, hi, rbase, h, b);
-  fused_issue_column<1>(a, tile_base, lo, hi, rbase, h, b);
-  fused_issue_column<2>(a, tile_base, lo, hi, rbase, h, b);
-  fused_issue_column<3>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<0, STREAM>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<1, STREAM>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<2, STREAM>(a, tile_base, lo, hi, rbase, h, b);
+  fused_issue_column<3, STREAM>(a, tile_base, lo, hi, rbase, h, b);
   const bool have_trs = a.t.pos != nullptr;
   // DIRTY_LOCAL becomes DIRTY_WORLD; from here on a set DIRTY_WORLD bit also says
   // that the fetched matrix is the local one or, where h.rebuild says so, the TRS
@@ -261,6 +277,7 @@ __device__ __forceinline__ void fused_issue_parent(const FusedArgs &a, const Fus
 // memory layout, through the wave's stretch of LDS: every wave store covers
 // 1 KiB of consecutive bytes. `want` marks the wave's threads whose matrix is
 // to be stored (wave-uniform value, bit = lane).
+template <bool STREAM>
 __device__ __forceinline__ void store_matrices(float4 *s_mat, float4 *dst, uint64_t round_base,
                                                float4 c0, float4 c1, float4 c2, float4 c3,
                                                unsigned long long want) {
@@ -283,7 +300,7 @@ __device__ __forceinline__ void store_matrices(float4 *s_mat, float4 *dst, uint6
     const float4 v = in0[r * 16 * MAT_LDS_STRIDE];
     const uint32_t chunk = (uint32_t)(want >> (16 * r)) & 0xffffu;  // scalar
     if ((chunk >> lane_bit) & 1u)
-      __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(out0 + r * 16 * 4));
+      store_once<STREAM>(reinterpret_cast<f32x4 *>(out0 + r * 16 * 4), f32x4{v.x, v.y, v.z, v.w});
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -342,7 +359,8 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
   }
 }
 
-template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false>
+template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
+          bool STREAM = false>
 // Four waves per SIMD below the root level: a level of 1M nodes is exactly one
 // resident set of blocks (4 per CU), and the register budget of 128 lets the
 // compiler keep the three pipeline stages apart. The root-level variant has no
@@ -401,8 +419,8 @@ k_propagate_classify(FusedArgs a) {
   FusedHead head_next, head_after;
   FusedBody body_next;
   FusedParent par_next;
-  if (active(0)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, 0u, head_next);
-  if (active(1)) fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
+  if (active(0)) fused_issue_head<HAS_PARENT, CULL, STREAM>(a, tile_base, lo, hi, 0u, head_next);
+  if (active(1)) fused_issue_head<HAS_PARENT, CULL, STREAM>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
   // merged top levels: thread e < anc_count looks after ancestor entry e
   float4 *anc_world = nullptr;   // [entry][4]: the ancestors' world matrices
   uint32_t *anc_moved = nullptr;  // [entry]: the ancestor's world matrix changes this frame
@@ -420,7 +438,7 @@ k_propagate_classify(FusedArgs a) {
   if (active(0)) {
     fused_resolve_head(a, tile_base, lo, hi, 0u, head_next);
     if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
-    fused_issue_body<CULL>(a, tile_base, lo, hi, 0u, head_next, body_next);
+    fused_issue_body<CULL, STREAM>(a, tile_base, lo, hi, 0u, head_next, body_next);
   }
   uint32_t updated_here = 0;
   if (TOP) {
@@ -498,10 +516,10 @@ k_propagate_classify(FusedArgs a) {
       fused_resolve_head(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
       // ahead of the matrices: loads return in issue order and the window is needed first
       if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
-      fused_issue_body<CULL>(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
+      fused_issue_body<CULL, STREAM>(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
     if (active(round + 2))
-      fused_issue_head<HAS_PARENT, CULL>(a, tile_base, lo, hi, rbase + 2u * FUSED_BLOCK, head_after);
+      fused_issue_head<HAS_PARENT, CULL, STREAM>(a, tile_base, lo, hi, rbase + 2u * FUSED_BLOCK, head_after);
     if (!active(round)) continue;
 
     // ---- columns in: memory layout -> compute layout ----------------------------
@@ -542,7 +560,7 @@ k_propagate_classify(FusedArgs a) {
     }
     {
       const unsigned long long rebuilt = __ballot(hd.rebuild);  // outside the level: never set
-      if (rebuilt != 0ull) store_matrices(s_mat, a.t.local, base, l0, l1, l2, l3, rebuilt);  // wave-uniform
+      if (rebuilt != 0ull) store_matrices<STREAM>(s_mat, a.t.local, base, l0, l1, l2, l3, rebuilt);  // wave-uniform
     }
     // Parents were finished by the previous level's launch, or recomputed by this
     // block (merged top levels).
@@ -603,7 +621,7 @@ k_propagate_classify(FusedArgs a) {
     if (valid) *at32(a.t.flags_out + base, t) = (uint8_t)fr;
     {
       const unsigned long long moved = __ballot(did_update);
-      if (moved != 0ull) store_matrices(s_mat, a.t.world, base, w0, w1, w2, w3, moved);  // wave-uniform
+      if (moved != 0ull) store_matrices<STREAM>(s_mat, a.t.world, base, w0, w1, w2, w3, moved);  // wave-uniform
     }
     updated_here += did_update ? 1u : 0u;  // per lane; summed when the block ends
     if (!CULL) continue;  // transform only

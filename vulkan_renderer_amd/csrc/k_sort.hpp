@@ -653,9 +653,28 @@ struct CandidateEmitArgs {
 // bytes - and drops them where they belong in the rows; behind one barrier the
 // block copies the rows out as they lie, nine pieces per thread, every wave store
 // 1 KiB of consecutive bytes.
+// A 16-byte load, marked as streaming when STREAM (read once, not worth a place
+// in a cache: for arrays larger than the last-level cache; smaller ones are found
+// there and lose by the hint).
+template <bool STREAM>
+__device__ __forceinline__ float4 load_streaming(const float4 *p) {
+  if constexpr (!STREAM) return *p;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool STREAM>
+__device__ __forceinline__ uint4 load_streaming(const uint4 *p) {
+  if constexpr (!STREAM) return *p;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 constexpr uint32_t EMIT_ROWS = 256;
 constexpr uint32_t EMIT_PIECES = 9;
 
+template <bool STREAM>
 __global__ __launch_bounds__(EMIT_ROWS) void k_emit_candidates(CandidateEmitArgs a) {
   __shared__ uint4 s_rows[EMIT_ROWS * EMIT_PIECES];  // 36 KiB: four blocks per CU
   const uint32_t t = threadIdx.x;
@@ -674,17 +693,17 @@ __global__ __launch_bounds__(EMIT_ROWS) void k_emit_candidates(CandidateEmitArgs
 #pragma unroll
   for (uint32_t j = 0; j < 2u; ++j) {  // piece q & 1 of the identity words of row q >> 1
     const uint32_t q = t + j * EMIT_ROWS;
-    id[j] = a.ident[source(q >> 1) * 2u + (q & 1u)];
+    id[j] = load_streaming<STREAM>(a.ident + source(q >> 1) * 2u + (q & 1u));
   }
 #pragma unroll
   for (uint32_t j = 0; j < 4u; ++j) {  // column q & 3 of the matrix of row q >> 2
     const uint32_t q = t + j * EMIT_ROWS;
     const uint64_t row = source(q >> 2);
     const uint64_t nd = a.node ? (uint64_t)a.node[row] : row;
-    col[j] = a.world[nd * 4u + (q & 3u)];
+    col[j] = load_streaming<STREAM>(a.world + nd * 4u + (q & 3u));
   }
-  const float4 sph = a.sphere[own];
-  const uint32_t cf = a.cflags[own];
+  const float4 sph = load_streaming<STREAM>(a.sphere + own);
+  const uint32_t cf = STREAM ? __builtin_nontemporal_load(a.cflags + own) : a.cflags[own];
 #pragma unroll
   for (uint32_t j = 0; j < 2u; ++j) {
     const uint32_t q = t + j * EMIT_ROWS;
@@ -714,8 +733,10 @@ __global__ __launch_bounds__(EMIT_ROWS) void k_emit_candidates(CandidateEmitArgs
 #pragma unroll
   for (uint32_t k = 0; k < EMIT_PIECES; ++k) {
     const uint32_t i = t + k * EMIT_ROWS;
-    // (streaming stores: nothing on the device reads the rows back)
-    if (i < pieces_here) __builtin_nontemporal_store(s_rows4[i], out4 + i);
+    if (i < pieces_here) {
+      if constexpr (STREAM) __builtin_nontemporal_store(s_rows4[i], out4 + i);
+      else out4[i] = s_rows4[i];
+    }
   }
 }
 

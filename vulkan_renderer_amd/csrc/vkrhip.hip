@@ -80,6 +80,10 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> top_anc_node, top_anc_info;
   bool top_enabled = true;  // VKRHIP_TOP_LEVELS=0 switches the merged launch off (A/B runs)
   bool top_balance = true;  // VKRHIP_TOP_BALANCE=0: 256-node blocks whatever their number
+  // Streaming loads and stores in the level launches of the fused kernel, for frames
+  // that do not fit the last-level cache. VKRHIP_STREAMING: 0 never, 1 always,
+  // unset: by the frame's footprint.
+  int streaming_mode = -1;
   uint32_t force_flags = 0;
   uint32_t fused_rounds = 0;  // tuning override (VKRHIP_FUSED_ROUNDS = 1, 2 or 4); 0 = by level size
   bool have_trs = false;
@@ -468,6 +472,7 @@ int check_range(vkrhip_ctx *c, uint64_t first, uint64_t count, uint64_t limit, c
 // list flattened to one entry per ancestor, root side first). Hierarchies
 // whose ranges are wide (parents not ascending with their children) get no
 // plan and run a launch per level.
+constexpr uint64_t kStreamingFootprint = 300ull << 20;  // bytes (measured crossover: about 2M nodes; the last-level cache holds 256 MB)
 constexpr uint32_t kTopMaxTiles = 1024;     // the merged launch covers at most this many tiles
 constexpr uint32_t kTopMaxAncestors = TOP_MAX_ANCESTORS;
 constexpr uint32_t kTopMaxSteps = 24;
@@ -624,6 +629,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   }
   if (const char *env = std::getenv("VKRHIP_TOP_LEVELS")) c->top_enabled = std::atoi(env) != 0;
   if (const char *env = std::getenv("VKRHIP_TOP_BALANCE")) c->top_balance = std::atoi(env) != 0;
+  if (const char *env = std::getenv("VKRHIP_STREAMING")) c->streaming_mode = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
@@ -1258,6 +1264,7 @@ static CullArgs cull_args(vkrhip_ctx *c) {
 }
 
 static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *rounds);
+static bool frame_streams(const vkrhip_ctx *c);
 
 // The merged launch of the top levels: ancestor tables, dynamic LDS behind the
 // cull tables.
@@ -1294,12 +1301,21 @@ static int launch_transform(vkrhip_ctx *c) {
     const uint64_t grid = fused_level_grid(c, l, &a.rounds);
     if (!grid) continue;
     a.t = transform_args(c, l);
-    if (l == 0 || !c->parent.p)
-      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<false, false, false, false>,
-                   dim3((unsigned)grid), dim3(FUSED_BLOCK), 0, a);
-    else
-      launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<true, false, false, false>,
-                   dim3((unsigned)grid), dim3(FUSED_BLOCK), 0, a);
+    const bool root = l == 0 || !c->parent.p;
+    const dim3 g((unsigned)grid), b(FUSED_BLOCK);
+    if (frame_streams(c)) {
+      if (root)
+        launch_timed(c, VKRHIP_TIMER_TRANSFORM, first,
+                     k_propagate_classify<false, false, false, false, false, true>, g, b, 0, a);
+      else
+        launch_timed(c, VKRHIP_TIMER_TRANSFORM, first,
+                     k_propagate_classify<true, false, false, false, false, true>, g, b, 0, a);
+    } else {
+      if (root)
+        launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<false, false, false, false>, g, b, 0, a);
+      else
+        launch_timed(c, VKRHIP_TIMER_TRANSFORM, first, k_propagate_classify<true, false, false, false>, g, b, 0, a);
+    }
     first = false;
   }
   c->force_flags = 0;
@@ -1341,7 +1357,16 @@ static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *roun
   return tiles * (FUSED_ROUNDS / *rounds);
 }
 
-template <bool HAS_PARENT, bool TOP = false>
+// Whether the level launches of a frame mark their loads and stores as streaming:
+// when what the frame reads and writes per node (about 160 bytes) does not fit
+// the last-level cache, so that nothing of it would be found there by the next
+// frame anyway.
+static bool frame_streams(const vkrhip_ctx *c) {
+  if (c->streaming_mode >= 0) return c->streaming_mode != 0;
+  return c->n_nodes * 160u > kStreamingFootprint;
+}
+
+template <bool HAS_PARENT, bool TOP = false, bool STREAM = false>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
                                  bool bounds_out, bool first) {
   const dim3 g(grid), b(FUSED_BLOCK);
@@ -1349,14 +1374,14 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
                          : cull_shared_bytes(a.c.views);
   if (ties) {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP, STREAM>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, false, true, TOP, STREAM>, g, b, lds, a);
   } else {
     if (bounds_out)
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, true, true, TOP, STREAM>, g, b, lds, a);
     else
-      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP>, g, b, lds, a);
+      launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM>, g, b, lds, a);
   }
 }
 
@@ -1390,10 +1415,17 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.t = transform_args(c, l);
     a.c = cull_args(c);
     a.seg_base = (uint32_t)seg_base;
-    if (l == 0 || !c->parent.p) {
-      launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
+    const bool root = l == 0 || !c->parent.p;
+    if (frame_streams(c)) {
+      if (root)
+        launch_fused_variant<false, false, true>(c, a, (unsigned)grid, ties, bounds_out, first);
+      else
+        launch_fused_variant<true, false, true>(c, a, (unsigned)grid, ties, bounds_out, first);
     } else {
-      launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
+      if (root)
+        launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
+      else
+        launch_fused_variant<true>(c, a, (unsigned)grid, ties, bounds_out, first);
     }
     first = false;
     seg_base += grid;
@@ -1620,15 +1652,17 @@ static int launch_candidates(vkrhip_ctx *c) {
   a.cflags = c->cflags.p;
   a.rows = c->cand_rows.p;
   a.n = c->n_cand;
-  hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_cand, EMIT_ROWS)), dim3(EMIT_ROWS), 0,
-                     c->stream, a);
+  // 260 bytes move per row: streaming loads and stores once that exceeds the last-level cache
+  const bool stream = c->streaming_mode >= 0 ? c->streaming_mode != 0 : c->n_cand * 260u > kStreamingFootprint;
+  const auto kernel = stream ? k_emit_candidates<true> : k_emit_candidates<false>;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(c->n_cand, EMIT_ROWS)), dim3(EMIT_ROWS), 0, c->stream, a);
   if (c->n_transmission) {
     TRY(dev_alloc(c, c->transmission_rows, c->n_transmission * 9));
     a.rows = c->transmission_rows.p;
     a.n = c->n_transmission;
     a.list = c->transmission_list.p;
-    hipLaunchKernelGGL(k_emit_candidates, dim3((unsigned)ceil_div(c->n_transmission, EMIT_ROWS)),
-                       dim3(EMIT_ROWS), 0, c->stream, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(c->n_transmission, EMIT_ROWS)), dim3(EMIT_ROWS), 0,
+                       c->stream, a);
   }
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
