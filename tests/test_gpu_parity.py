@@ -478,6 +478,79 @@ def test_merged_top_levels_balanced(oracle, monkeypatch, balance):
         assert_bits_equal(hs.read_world(), want_world, "world matrices, transform only")
 
 
+@pytest.mark.parametrize("streaming", ["1", "0"])
+def test_streaming_accesses_forced(oracle, monkeypatch, streaming):
+    """Frames larger than the last-level cache run the level launches and the
+    candidate rows with streaming loads and stores (other instantiations of the
+    kernels). VKRHIP_STREAMING=1 forces them on a small scene: a first frame that
+    rebuilds every local matrix from its TRS, both candidate streams, a partial
+    TRS change, a frame with nothing moved, a few subtrees moved through their
+    local matrices, and a transform-only frame - every output against the oracle."""
+    synth = _synth()
+    monkeypatch.setenv("VKRHIP_STREAMING", streaming)
+    sc = synth.deep_scene(150000, depth=6, seed=31, fanout=6, roots=5, blend_fraction=0.2,
+                          transmissive_fraction=0.05, no_bounds_fraction=0.01)
+    n = sc.n
+    vs = synth.camera_views(cascades=2, far=700.0)
+    planes, required = view_set(vs)
+    rng = np.random.default_rng(9)
+    stages = STAGE_TRANSFORM | STAGE_CULL | STAGE_TRANSPARENT | STAGE_CANDIDATES
+    with hip_scene_for(sc, 3) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame(stages)
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+        info = compare_frame(hs, ref, sc)
+        assert hs.read_candidates().tobytes() == ref["payload"]["gpu_candidates"].tobytes()
+        expect = ref["payload"]["transmission_candidates"]
+        got = hs.read_transmission_candidates(info.transmission_gpu_candidate_count)
+        assert got.tobytes() == expect.tobytes(), "transmission_gpu_candidates rows"
+        local, world = ref["local"], ref["world"]
+        # some nodes get a new position (pass 1 for them, pass 2 for their subtrees)
+        moved = np.unique(np.concatenate([rng.integers(0, 40, 3), rng.integers(0, n, 200)]))
+        pos = sc.pos.copy()
+        pos[moved, :3] += np.float32(1.25)
+        for i in moved:
+            hs.upload_trs(pos[i:i + 1], sc.quat[i:i + 1], sc.scale[i:i + 1], first=int(i))
+        flags = np.zeros(n, np.uint8)
+        flags[moved] = DIRTY_LOCAL
+        local, world, flags_out, dirty = oracle.scene_update(sc.parent, local=local, world=world, flags=flags,
+                                                             pos=pos, quat=sc.quat, scale=sc.scale)
+        hs.frame(stages)
+        assert hs.frame_info().nodes_updated == dirty.shape[0]
+        assert_bits_equal(hs.read_locals(), local, "locals after the partial change")
+        assert (hs.read_node_flags() == flags_out).all()
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, world=world)
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert_bits_equal(hs.read_world(), world, "world matrices after the partial change")
+        assert hs.read_candidates().tobytes() == ref["payload"]["gpu_candidates"].tobytes()
+        # nothing moved
+        hs.frame(stages)
+        assert hs.frame_info().nodes_updated == 0
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert_bits_equal(hs.read_world(), world, "world matrices, nothing moved")
+        # subtrees moved through their local matrices
+        flags = np.zeros(n, np.uint8)
+        flags[rng.integers(0, 200, 5)] = DIRTY_WORLD
+        flags[rng.integers(0, n, 50)] = DIRTY_WORLD
+        moved = np.flatnonzero(flags)
+        local = local.copy()
+        local[moved, 12] -= np.float32(0.75)
+        hs.upload_locals(local)
+        hs.upload_node_flags(flags)
+        _, world, flags_out, dirty = oracle.scene_update(sc.parent, local=local, flags=flags, world=world)
+        hs.frame(stages)
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection, world=world)
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert_bits_equal(hs.read_world(), world, "world matrices, subtrees moved")
+        assert (hs.read_node_flags() == flags_out).all()
+        assert hs.frame_info().nodes_updated == dirty.shape[0] > 0
+        # transform only
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame(STAGE_TRANSFORM)
+        assert hs.frame_info().nodes_updated == n
+        assert_bits_equal(hs.read_world(), world, "world matrices, transform only")
+
+
 @pytest.mark.parametrize("overlap", ["0", "2"])
 @pytest.mark.parametrize("blend_fraction", [0.02, 0.6])
 def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_fraction):
