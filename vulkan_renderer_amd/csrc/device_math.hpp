@@ -212,19 +212,24 @@ __device__ __forceinline__ uniform_ptr<float> as_uniform(const float4 *p) {
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool sphere_visible(uniform_ptr<float> paired, float cx, float cy,
                                                float cz, float radius) {
-  bool culled = false;
   const float neg_r = -radius;
   const float2v x = {cx, cx}, y = {cy, cy}, z = {cz, cz};
+  float2v dist[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const float2v nx = {paired[j * 8 + 0], paired[j * 8 + 1]};
     const float2v ny = {paired[j * 8 + 2], paired[j * 8 + 3]};
     const float2v nz = {paired[j * 8 + 4], paired[j * 8 + 5]};
     const float2v d = {paired[j * 8 + 6], paired[j * 8 + 7]};
-    const float2v dist = ((nx * x + ny * y) + nz * z) + d;
-    culled = culled || (dist.x < neg_r) || (dist.y < neg_r);
+    dist[j] = ((nx * x + ny * y) + nz * z) + d;
   }
-  return !culled;
+  // "some plane has dist < -radius" is "the smallest distance is < -radius": the
+  // minimum of IEEE minNum skips NaN distances exactly as their comparisons would
+  // have come out false, and a NaN radius makes the one comparison false as it
+  // made all six. Two three-way minima, one two-way, one comparison.
+  const float nearest = fminf(fminf(fminf(dist[0].x, dist[0].y), dist[1].x),
+                              fminf(fminf(dist[1].y, dist[2].x), dist[2].y));
+  return !(nearest < neg_r);
 }
 
 }  // namespace vkr
