@@ -267,14 +267,31 @@ def measure_dropin(setup, steps, fence) -> dict:
         hs._ok(lib.vkrhip_read_transparent(hs.ctx, raw.transparent_draw_count, N.ptr(draws),
                                            N.ptr(inst), None, None))
     host_s = (time.perf_counter() - t0) / host_steps
+    # the same copies into page-locked memory from the library (vkrhip_host_alloc)
+    rows_p = hs.host_buffer(n * CANDIDATE_ROW_BYTES)
+    draws_p, inst_p = hs.host_buffer(max(t, 1) * 48), hs.host_buffer(max(t, 1) * 80)
+    t0 = time.perf_counter()
+    for _ in range(host_steps):
+        frame()
+        hs._ok(lib.vkrhip_get_frame_info(hs.ctx, C.byref(raw)))
+        hs._ok(lib.vkrhip_read_candidates(hs.ctx, 0, n, N.ptr(rows_p)))
+        hs._ok(lib.vkrhip_read_transparent(hs.ctx, raw.transparent_draw_count, N.ptr(draws_p),
+                                           N.ptr(inst_p), None, None))
+    pinned_s = (time.perf_counter() - t0) / host_steps
+    same = bool((rows_p == rows).all() and (draws_p == draws).all() and (inst_p == inst).all())
+    del rows_p, draws_p, inst_p
+    hs.host_buffers_free()
     emit_bytes = n * (CANDIDATE_IN_BYTES + CANDIDATE_ROW_BYTES)
     return {
         "stages": "transform + cull + sort + 144-byte candidate rows (STAGE_ALL | STAGE_CANDIDATES)",
         "ms_per_step": device_s * 1e3, "value": n / device_s,
         "ms_per_step_with_host_copies": host_s * 1e3, "value_with_host_copies": n / host_s,
+        "ms_per_step_with_host_copies_pinned": pinned_s * 1e3, "value_with_host_copies_pinned": n / pinned_s,
+        "pinned_copies_equal_pageable": same,
         "host_copies": f"frame counters, {n} candidate rows ({n * CANDIDATE_ROW_BYTES / 1e6:.0f} MB), "
-                       f"{t} sorted draws + instances into pageable host memory, every frame "
-                       "(the reference caps a frame at 262144 rows = 38 MB)",
+                       f"{t} sorted draws + instances into pageable host memory, every frame; _pinned: "
+                       "the same into page-locked memory from vkrhip_host_alloc "
+                       "(the reference caps a frame at 262144 rows = 38 MB, see at_reference_capacity)",
         "roofline_emit_candidates": {
             "bound": "hbm", "kernel": "k_emit_candidates", "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "achieved": round(emit_bytes / cand_s / 1e9, 1) if cand_s > 0 else 0.0,
@@ -282,6 +299,75 @@ def measure_dropin(setup, steps, fence) -> dict:
             "avg_launch_us": round(cand_s * 1e6, 2),
             "algorithmic_bytes_per_step": int(emit_bytes),
         },
+    }
+
+
+REFERENCE_ROW_CAPACITY = 262144  # VKR_GPU_DRAW_CANDIDATE_CAPACITY, application.h:703-711
+
+
+def measure_reference_capacity(local_rank: int, seed: int, fence, cpu_seconds: float) -> dict:
+    """The largest frame the reference itself accepts (262144 source rows), as a
+    drop-in sees it: the whole path with candidate rows, the payload arrays
+    copied to page-locked host memory, the host blocked until they are there -
+    next to the CPU restatement on the same scene (one host core)."""
+    import ctypes as C
+    from oracle import pyoracle
+    from vulkan_renderer_amd import _native as N
+    workload = dict(WORKLOADS["deep16m"], n=REFERENCE_ROW_CAPACITY)
+    setup = Setup("capacity", workload, 0, local_rank, seed, 1)
+    hs, n, lib, sc = setup.hs, setup.n, setup.hs.lib, setup.sc
+    stages = N.STAGE_ALL | N.STAGE_CANDIDATES
+    raw = N.FrameInfo()
+    rows = hs.host_buffer(n * CANDIDATE_ROW_BYTES)
+    draws, inst = hs.host_buffer(n * 48), hs.host_buffer(n * 80)
+
+    def frame():
+        hs.mark_all(N.DIRTY_WORLD)
+        hs.frame(stages)
+        hs._ok(lib.vkrhip_get_frame_info(hs.ctx, C.byref(raw)))
+        hs._ok(lib.vkrhip_read_candidates(hs.ctx, 0, n, N.ptr(rows)))
+        hs._ok(lib.vkrhip_read_transparent(hs.ctx, raw.transparent_draw_count, N.ptr(draws),
+                                           N.ptr(inst), None, None))
+
+    for _ in range(3):
+        frame()
+    fence()
+    steps = 50
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    gpu_s = (time.perf_counter() - t0) / steps
+    t = raw.transparent_draw_count
+
+    pyoracle.build()
+    o = pyoracle.Oracle()
+    local, world, _, _ = o.scene_update(sc.parent, pos=sc.pos, quat=sc.quat, scale=sc.scale,
+                                        flags=np.full(sc.n, N.DIRTY_LOCAL, np.uint8))
+    pay = o.build_world_payload(world, None, sc.ident, sc.matbits, sc.bounds, setup.vs.view,
+                                setup.vs.projection)
+    # the reference's loop structure as one C call per frame, like cpu_baseline()
+    h = o.baseline_create(sc.parent, local, None, sc.ident, sc.matbits, sc.bounds, setup.planes,
+                          setup.required, setup.vs.view, setup.vs.projection)
+    o.baseline_frame(h)
+    frames, t0 = 0, time.perf_counter()
+    while frames < 3 or time.perf_counter() - t0 < min(cpu_seconds, 1.0):
+        o.baseline_frame(h)
+        frames += 1
+    cpu_s = (time.perf_counter() - t0) / frames
+    o.baseline_destroy(h)
+    same = bool(rows.tobytes() == pay["gpu_candidates"].tobytes()
+                and draws[: t * 48].tobytes() == pay["draws"].tobytes()
+                and inst[: t * 80].tobytes() == pay["instances"].tobytes())
+    del rows, draws, inst
+    setup.close()
+    return {
+        "rows": n, "views": setup.views, "hierarchy_depth": len(sc.level_offsets) - 1,
+        "ms_per_frame": gpu_s * 1e3, "value": n / gpu_s,
+        "what": "transform + cull + sort + candidate rows, frame counters read, candidate rows "
+                f"({n * CANDIDATE_ROW_BYTES / 1e6:.0f} MB) and {t} sorted draws + instances copied to "
+                "page-locked host memory, host blocked until done, every frame",
+        "cpu_ms_per_frame": cpu_s * 1e3, "cpu_value": n / cpu_s, "cpu_cores": 1,
+        "host_arrays_equal_cpu": same,
     }
 
 
@@ -433,14 +519,20 @@ def main() -> int:
     }
 
     single = rank == 0 and world == 1
+    want_capacity = False
     if single and not args.no_dropin and args.submeshes == 1 and exchange is None:
         result["dropin"] = measure_dropin(setup, min(args.steps, 10), fence)
+        want_capacity = not args.no_cpu_baseline and not overridden
     if single and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sc, setup.planes, setup.required, setup.vs, args.cpu_seconds)
     if world > 1:
         dist.barrier()  # no rank tears its communicator down while another still uses it
     setup.close()
     del setup, hs, sc
+
+    if want_capacity:
+        result["dropin"]["at_reference_capacity"] = measure_reference_capacity(local_rank, args.seed, fence,
+                                                                               args.cpu_seconds)
 
     if single and not args.no_secondary and not overridden and exchange is None:
         # the other single-GPU configurations, each with its own roofline (shorter runs)

@@ -296,6 +296,15 @@ typedef struct vkrhip_world_payload {
 int vkrhip_fill_world_payload(vkrhip_ctx *ctx, vkrhip_world_payload *out_payload,
                               vkrhip_visibility_stats *out_stats);
 
+/* Page-locked host memory for the destinations of the vkrhip_read_* copies below
+ * (the arrays of the VkrWorldPassPayload a host-side consumer reads, which the
+ * reference takes from its frame scratch allocator, application.h:1415-1419): a
+ * copy into it runs at the PCIe rate, about four times that of pageable memory
+ * (2.4 GB of candidate rows: 44 ms against 174 ms). The memory belongs to the
+ * caller until vkrhip_host_free; any host pointer still works as a destination. */
+int vkrhip_host_alloc(vkrhip_ctx *ctx, uint64_t bytes, void **out_pointer);
+int vkrhip_host_free(vkrhip_ctx *ctx, void *pointer);
+
 /* Synchronous device-to-host copies of outputs (after the frame completes). */
 int vkrhip_read_world(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out16);
 int vkrhip_read_locals(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out16);

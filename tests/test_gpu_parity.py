@@ -551,6 +551,39 @@ def test_streaming_accesses_forced(oracle, monkeypatch, streaming):
         assert_bits_equal(hs.read_world(), world, "world matrices, transform only")
 
 
+def test_page_locked_host_buffers(oracle):
+    """vkrhip_host_alloc: the read copies land in page-locked memory of the
+    library exactly as they land in ordinary memory; zero bytes and a null
+    result pointer are argument errors, freeing null is not."""
+    import ctypes as C
+    from vulkan_renderer_amd import _native as N
+    synth = _synth()
+    sc = synth.deep_scene(30000, depth=5, seed=12, fanout=6, roots=4, blend_fraction=0.3)
+    vs = synth.camera_views(cascades=1, far=600.0)
+    planes, required = view_set(vs)
+    with hip_scene_for(sc, 2) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame(STAGE_TRANSFORM | STAGE_CULL | STAGE_TRANSPARENT | STAGE_CANDIDATES)
+        info = hs.frame_info()
+        t = info.transparent_draw_count
+        assert t > 100
+        rows = hs.host_buffer(sc.n * 144)
+        draws, inst = hs.host_buffer(t * 48), hs.host_buffer(t * 80)
+        hs._ok(hs.lib.vkrhip_read_candidates(hs.ctx, 0, sc.n, N.ptr(rows)))
+        hs._ok(hs.lib.vkrhip_read_transparent(hs.ctx, t, N.ptr(draws), N.ptr(inst), None, None))
+        assert rows.tobytes() == hs.read_candidates().tobytes()
+        want_draws, want_inst, _, _ = hs.read_transparent(t)
+        assert draws.tobytes() == want_draws.tobytes() and inst.tobytes() == want_inst.tobytes()
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+        assert rows.tobytes() == ref["payload"]["gpu_candidates"].tobytes()
+        del rows, draws, inst
+        hs.host_buffers_free()
+        p = C.c_void_p()
+        assert hs.lib.vkrhip_host_alloc(hs.ctx, 0, C.byref(p)) == N.ERR_ARG and not p.value
+        assert hs.lib.vkrhip_host_alloc(hs.ctx, 64, None) == N.ERR_ARG
+        assert hs.lib.vkrhip_host_free(hs.ctx, None) == 0
+
+
 @pytest.mark.parametrize("overlap", ["0", "2"])
 @pytest.mark.parametrize("blend_fraction", [0.02, 0.6])
 def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_fraction):

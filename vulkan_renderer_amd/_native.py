@@ -54,6 +54,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_shadow_fit_cascade", "vkrhip_shadow_fit_relevant_caster_z",
     "vkrhip_shadow_quantize_extent_up", "vkrhip_shadow_apply_fit_hysteresis",
     "vkrhip_shadow_build_view_set", "vkrhip_get_caster_bounds", "vkrhip_gltf_read_nodes",
+    "vkrhip_host_alloc", "vkrhip_host_free",
 ]
 
 
@@ -250,6 +251,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_read_transparent_visible.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_transparent.argtypes = [vp, u64, vp, vp, vp, vp]
     L.vkrhip_read_candidates.argtypes = [vp, u64, u64, vp]
+    L.vkrhip_host_alloc.argtypes = [vp, u64, C.POINTER(C.c_void_p)]
+    L.vkrhip_host_free.argtypes = [vp, vp]
     L.vkrhip_read_world_bounds.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_candidate_prep.argtypes = [vp, u64, u64, vp, vp]
     L.vkrhip_set_publication.argtypes = [vp, vp, u32, vp, u32, vp, u32]

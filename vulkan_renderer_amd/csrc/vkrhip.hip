@@ -1904,6 +1904,23 @@ static int read_back(vkrhip_ctx *c, void *dst, const void *src, size_t bytes) {
   return VKRHIP_OK;
 }
 
+int vkrhip_host_alloc(vkrhip_ctx *c, uint64_t bytes, void **out_pointer) {
+  if (!c || !out_pointer) return c ? fail(c, VKRHIP_ERR_ARG, "host_alloc: null out_pointer") : VKRHIP_ERR_ARG;
+  *out_pointer = nullptr;
+  if (bytes == 0) return fail(c, VKRHIP_ERR_ARG, "host_alloc: zero bytes");
+  TRY(bind_device(c));
+  HIP_TRY(c, hipHostMalloc(out_pointer, bytes, hipHostMallocDefault));
+  return VKRHIP_OK;
+}
+
+int vkrhip_host_free(vkrhip_ctx *c, void *pointer) {
+  if (!c) return VKRHIP_ERR_ARG;
+  if (!pointer) return VKRHIP_OK;
+  TRY(bind_device(c));
+  HIP_TRY(c, hipHostFree(pointer));
+  return VKRHIP_OK;
+}
+
 int vkrhip_read_world(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out16) {
   if (!c || !out16) return VKRHIP_ERR_ARG;
   TRY(check_range(c, first, count, c->cfg.max_nodes, "read_world"));

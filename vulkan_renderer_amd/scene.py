@@ -134,6 +134,9 @@ class HipScene:
     # ---- lifetime -------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "ctx", None) is not None and self.ctx:
+            for address in getattr(self, "_host_buffers", []):
+                self.lib.vkrhip_host_free(self.ctx, C.c_void_p(address))
+            self._host_buffers = []
             self.lib.vkrhip_destroy(self.ctx)
             self.ctx = None
 
@@ -307,6 +310,21 @@ class HipScene:
         self._ok(self.lib.vkrhip_read_transparent(self.ctx, count, N.ptr(draws), N.ptr(inst),
                                                   N.ptr(keys), N.ptr(src)))
         return draws, inst, keys, src
+
+    def host_buffer(self, nbytes: int) -> np.ndarray:
+        """Page-locked host bytes (vkrhip_host_alloc) as a uint8 array, for the
+        destinations of read copies; released by host_buffer_free or close()."""
+        p = C.c_void_p()
+        self._ok(self.lib.vkrhip_host_alloc(self.ctx, max(int(nbytes), 1), C.byref(p)))
+        self._host_buffers = getattr(self, "_host_buffers", [])
+        self._host_buffers.append(p.value)
+        return np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 1)).from_address(p.value))
+
+    def host_buffers_free(self) -> None:
+        """Releases every host_buffer() of this scene (their arrays become invalid)."""
+        for address in getattr(self, "_host_buffers", []):
+            self._ok(self.lib.vkrhip_host_free(self.ctx, C.c_void_p(address)))
+        self._host_buffers = []
 
     def read_candidates(self) -> np.ndarray:
         out = np.zeros(self.n_candidates, CANDIDATE_DT)
