@@ -307,9 +307,10 @@ REFERENCE_ROW_CAPACITY = 262144  # VKR_GPU_DRAW_CANDIDATE_CAPACITY, application.
 
 def measure_reference_capacity(local_rank: int, seed: int, fence, cpu_seconds: float) -> dict:
     """The largest frame the reference itself accepts (262144 source rows), as a
-    drop-in sees it: the whole path with candidate rows, the payload arrays
-    copied to page-locked host memory, the host blocked until they are there -
-    next to the CPU restatement on the same scene (one host core)."""
+    drop-in sees it: the whole path with candidate rows, then the reference's own
+    output struct filled by vkrhip_fill_world_payload (arrays in page-locked host
+    memory, the host blocked until they are there) - next to the CPU restatement
+    on the same scene (one host core)."""
     import ctypes as C
     from oracle import pyoracle
     from vulkan_renderer_amd import _native as N
@@ -317,17 +318,12 @@ def measure_reference_capacity(local_rank: int, seed: int, fence, cpu_seconds: f
     setup = Setup("capacity", workload, 0, local_rank, seed, 1)
     hs, n, lib, sc = setup.hs, setup.n, setup.hs.lib, setup.sc
     stages = N.STAGE_ALL | N.STAGE_CANDIDATES
-    raw = N.FrameInfo()
-    rows = hs.host_buffer(n * CANDIDATE_ROW_BYTES)
-    draws, inst = hs.host_buffer(n * 48), hs.host_buffer(n * 80)
+    payload, stats = N.WorldPayload(), N.VisibilityStats()
 
-    def frame():
+    def frame():  # what the call-through of INTEGRATION.md does every frame
         hs.mark_all(N.DIRTY_WORLD)
         hs.frame(stages)
-        hs._ok(lib.vkrhip_get_frame_info(hs.ctx, C.byref(raw)))
-        hs._ok(lib.vkrhip_read_candidates(hs.ctx, 0, n, N.ptr(rows)))
-        hs._ok(lib.vkrhip_read_transparent(hs.ctx, raw.transparent_draw_count, N.ptr(draws),
-                                           N.ptr(inst), None, None))
+        hs._ok(lib.vkrhip_fill_world_payload(hs.ctx, C.byref(payload), C.byref(stats)))
 
     for _ in range(3):
         frame()
@@ -337,7 +333,10 @@ def measure_reference_capacity(local_rank: int, seed: int, fence, cpu_seconds: f
     for _ in range(steps):
         frame()
     gpu_s = (time.perf_counter() - t0) / steps
-    t = raw.transparent_draw_count
+    t = payload.transparent_draw_count
+    rows = C.string_at(payload.gpu_candidates, payload.gpu_candidate_count * CANDIDATE_ROW_BYTES)
+    draws = C.string_at(payload.transparent_draws, t * 48) if t else b""
+    inst = C.string_at(payload.instances, t * 80) if t else b""
 
     pyoracle.build()
     o = pyoracle.Oracle()
@@ -355,17 +354,18 @@ def measure_reference_capacity(local_rank: int, seed: int, fence, cpu_seconds: f
         frames += 1
     cpu_s = (time.perf_counter() - t0) / frames
     o.baseline_destroy(h)
-    same = bool(rows.tobytes() == pay["gpu_candidates"].tobytes()
-                and draws[: t * 48].tobytes() == pay["draws"].tobytes()
-                and inst[: t * 80].tobytes() == pay["instances"].tobytes())
-    del rows, draws, inst
+    same = bool(rows == pay["gpu_candidates"].tobytes() and draws == pay["draws"].tobytes()
+                and inst == pay["instances"].tobytes()
+                and stats.objects_tested == int(pay["stats"][0])
+                and stats.objects_culled_camera == int(pay["stats"][1]))
     setup.close()
     return {
         "rows": n, "views": setup.views, "hierarchy_depth": len(sc.level_offsets) - 1,
         "ms_per_frame": gpu_s * 1e3, "value": n / gpu_s,
-        "what": "transform + cull + sort + candidate rows, frame counters read, candidate rows "
-                f"({n * CANDIDATE_ROW_BYTES / 1e6:.0f} MB) and {t} sorted draws + instances copied to "
-                "page-locked host memory, host blocked until done, every frame",
+        "what": "vkrhip_frame(transform + cull + sort + candidate rows) + vkrhip_fill_world_payload: "
+                f"the VkrWorldPassPayload with its candidate rows ({n * CANDIDATE_ROW_BYTES / 1e6:.0f} MB), "
+                f"{t} sorted draws + instances in page-locked host memory and the visibility stats, "
+                "host blocked until they are there, every frame",
         "cpu_ms_per_frame": cpu_s * 1e3, "cpu_value": n / cpu_s, "cpu_cores": 1,
         "host_arrays_equal_cpu": same,
     }
