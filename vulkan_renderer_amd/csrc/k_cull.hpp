@@ -182,6 +182,28 @@ struct CullArgs {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Sixteen bytes that only pass through registers on their way from global memory
+// to LDS. As the native vector type the copies are one load and one store; as
+// float4 (a struct) the compiler chains block copies through a stack slot.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// STREAM: a frame whose arrays do not fit the last-level cache (256 MB) reads
+// every input once and writes every output once, so keeping any of it in a
+// cache only evicts what IS read twice (the parents' matrices); such frames
+// mark their loads and stores as streaming. A scene that fits the cache is found
+// there by the next frame and must not use the hint (1M nodes: 30 -> 32.5 us).
+template <bool STREAM, typename T>
+__device__ __forceinline__ T load_once(const T *p) {
+  if constexpr (STREAM) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool STREAM, typename T>
+__device__ __forceinline__ void store_once(T *p, T v) {
+  if constexpr (STREAM) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+
 // LDS working set of one classify block, carved out of dynamic shared memory
 // (its size depends on the view count). A slot is one (round, wave) pair, i.e.
 // 64 consecutive candidates:
@@ -556,7 +578,10 @@ __device__ __forceinline__ void segment_empty(const CullArgs &a, uint64_t seg) {
 // 256. With the identity candidate->node mapping the matrices arrive as
 // coalesced 16-byte loads staged through LDS (thread t then reads its own four
 // columns); otherwise each thread gathers its node's matrix.
-template <bool IDENTITY, bool TIES, bool BOUNDS_OUT, bool HZB = false>
+// STREAM: streaming loads for what is read once (see load_once); the matrices
+// gathered through a candidate -> node mapping are shared by a node's rows and
+// keep the default policy.
+template <bool IDENTITY, bool TIES, bool BOUNDS_OUT, bool HZB = false, bool STREAM = false>
 __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
   __shared__ float4 s_mat[IDENTITY ? CULL_BLOCK * MAT_LDS_STRIDE : 1];
   CullShared s = cull_shared_init(a.views);
@@ -572,8 +597,9 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
 #pragma unroll
   for (int round = 0; round < CULL_ROUNDS; ++round) {
     const uint64_t i = min(first + (uint64_t)round * CULL_BLOCK + t, last);
-    ls_r[round] = a.sphere[i];
-    cf_r[round] = a.cflags[i];
+    const f32x4 ls = load_once<STREAM>(reinterpret_cast<const f32x4 *>(a.sphere) + i);
+    ls_r[round] = make_float4(ls.x, ls.y, ls.z, ls.w);
+    cf_r[round] = load_once<STREAM>(a.cflags + i);
   }
 #pragma unroll
   for (int round = 0; round < CULL_ROUNDS; ++round) {
@@ -588,10 +614,13 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
       const uint64_t last4 = a.n * 4u - 1u;
       // (named values: as an array the four loads are kept in scratch memory
       // between the load and the LDS store)
-      const float4 v0 = a.world[min(base * 4u + t, last4)];
-      const float4 v1 = a.world[min(base * 4u + t + 256u, last4)];
-      const float4 v2 = a.world[min(base * 4u + t + 512u, last4)];
-      const float4 v3 = a.world[min(base * 4u + t + 768u, last4)];
+      const f32x4 *wm = reinterpret_cast<const f32x4 *>(a.world);
+      const f32x4 u0 = load_once<STREAM>(wm + min(base * 4u + t, last4));
+      const f32x4 u1 = load_once<STREAM>(wm + min(base * 4u + t + 256u, last4));
+      const f32x4 u2 = load_once<STREAM>(wm + min(base * 4u + t + 512u, last4));
+      const f32x4 u3 = load_once<STREAM>(wm + min(base * 4u + t + 768u, last4));
+      const float4 v0 = make_float4(u0.x, u0.y, u0.z, u0.w), v1 = make_float4(u1.x, u1.y, u1.z, u1.w);
+      const float4 v2 = make_float4(u2.x, u2.y, u2.z, u2.w), v3 = make_float4(u3.x, u3.y, u3.z, u3.w);
       __syncthreads();  // the previous round's readers of s_mat are done
       s_mat[(t >> 2) * MAT_LDS_STRIDE + (t & 3u)] = v0;
       s_mat[((t + 256u) >> 2) * MAT_LDS_STRIDE + (t & 3u)] = v1;
@@ -604,7 +633,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
       m.c[2] = p[2];
       m.c[3] = p[3];
     } else {
-      const float4 *p = a.world + (uint64_t)a.node[min(i, last)] * 4u;
+      const float4 *p = a.world + (uint64_t)load_once<STREAM>(a.node + min(i, last)) * 4u;
       m.c[0] = p[0];
       m.c[1] = p[1];
       m.c[2] = p[2];

@@ -81,10 +81,6 @@ __device__ __forceinline__ uint32_t sub_slot(int r) {
   return (threadIdx.x & ~63u) + (uint32_t)r * 16u + ((threadIdx.x & 63u) >> 2);
 }
 
-// Sixteen bytes that only pass through registers on their way from global memory
-// to LDS. As the native vector type the copies are one load and one store; as
-// float4 (a struct) the compiler chains block copies through a stack slot.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Element `index` of an array whose base is the same for the whole wave, addressed
 // as that base (a scalar register pair) plus a 32-bit byte offset per lane: no
@@ -98,22 +94,6 @@ __device__ __forceinline__ const T *at32(const T *uniform_base, uint32_t index) 
 template <typename T>
 __device__ __forceinline__ T *at32(T *uniform_base, uint32_t index) {
   return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
-}
-
-// STREAM: a frame whose arrays do not fit the last-level cache (256 MB) reads
-// every input once and writes every output once, so keeping any of it in a
-// cache only evicts what IS read twice (the parents' matrices); such frames
-// mark their loads and stores as streaming. A scene that fits the cache is found
-// there by the next frame and must not use the hint (1M nodes: 30 -> 32.5 us).
-template <bool STREAM, typename T>
-__device__ __forceinline__ T load_once(const T *p) {
-  if constexpr (STREAM) return __builtin_nontemporal_load(p);
-  return *p;
-}
-template <bool STREAM, typename T>
-__device__ __forceinline__ void store_once(T *p, T v) {
-  if constexpr (STREAM) __builtin_nontemporal_store(v, p);
-  else *p = v;
 }
 
 // What one thread loads for one round, in two dependent steps: the head (flags,

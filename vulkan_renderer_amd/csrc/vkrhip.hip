@@ -1456,6 +1456,22 @@ static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned g
     }
     return;
   }
+  // 85 bytes move per row: streaming loads once that exceeds the last-level cache
+  const bool stream = c->streaming_mode >= 0 ? c->streaming_mode != 0 : c->n_cand * 85u > kStreamingFootprint;
+  if (stream) {
+    if (ties) {
+      if (bounds_out)
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, true, false, true>, g, b, lds, a);
+      else
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, false, false, true>, g, b, lds, a);
+    } else {
+      if (bounds_out)
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, false, true, false, true>, g, b, lds, a);
+      else
+        launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, false, false, false, true>, g, b, lds, a);
+    }
+    return;
+  }
   if (ties) {
     if (bounds_out)
       launch_timed(c, VKRHIP_TIMER_CLASSIFY, true, k_classify<IDENTITY, true, true>, g, b, lds, a);
