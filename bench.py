@@ -320,7 +320,7 @@ def measure_reference_capacity(local_rank: int, seed: int, fence, cpu_seconds: f
     stages = N.STAGE_ALL | N.STAGE_CANDIDATES
     payload, stats = N.WorldPayload(), N.VisibilityStats()
 
-    def frame():  # what the call-through of INTEGRATION.md does every frame
+    def frame():  # what a call-through behind application_build_world_payload does every frame
         hs.mark_all(N.DIRTY_WORLD)
         hs.frame(stages)
         hs._ok(lib.vkrhip_fill_world_payload(hs.ctx, C.byref(payload), C.byref(stats)))
