@@ -339,15 +339,17 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
   }
 }
 
-template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
-          bool STREAM = false>
-// Four waves per SIMD below the root level: a level of 1M nodes is exactly one
+// Waves per SIMD. Four below the root level: a level of 1M nodes is exactly one
 // resident set of blocks (4 per CU), and the register budget of 128 lets the
 // compiler keep the three pipeline stages apart. The root-level variant has no
 // parent window and no matrix product to hold and fits five waves, which pays
-// when many views make the classification the longer part of a round.
+// when many views make the classification the longer part of a round; without
+// the cull phase it needs 71 registers and fits six (8M roots: 197 -> 193 us).
+constexpr int fused_waves(bool has_parent, bool cull) { return has_parent ? 4 : (cull ? 5 : 6); }
+template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
+          bool STREAM = false>
 __global__ __launch_bounds__(FUSED_BLOCK)
-    __attribute__((amdgpu_waves_per_eu(HAS_PARENT ? 4 : 5, HAS_PARENT ? 4 : 5))) void
+    __attribute__((amdgpu_waves_per_eu(fused_waves(HAS_PARENT, CULL), fused_waves(HAS_PARENT, CULL)))) void
 k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ float4 s_par[HAS_PARENT && !TOP ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
