@@ -684,6 +684,36 @@ int vkrhip_gltf_read_nodes(const char *json, uint64_t length, uint32_t scene, ui
                            float *quat4, float *scale4, int32_t *mesh, uint8_t *has_matrix,
                            float *matrix16);
 
+/* ---- scene files ---------------------------------------------------------------
+ * "entities" of one of the reference's scene files (assets/scenes/ *.scene.json,
+ * version 2) as per-entity arrays in file order: what scene_json_parse_parent /
+ * _transform / _mesh / _shape take from an entity
+ * (lib/src/renderer/resources/loaders/scene_loader.c:1243-1310,1311-1330,1417-1475),
+ * restricted to what the scene path consumes. Host code, the JSON walker of the
+ * glTF reader.
+ *   capacity     room in the arrays; with fewer, info is filled and
+ *                VKRHIP_ERR_CAPACITY returned (call once with 0 to size them)
+ *   parent       index of the parent entity, 0xffffffff for none ("parent" absent or null)
+ *   pos4 / quat4 (x, y, z, w) / scale4   "transform": "pos", "rot", "scale";
+ *                0 / identity / 1 where absent
+ *   kind         0 nothing to draw, 1 a "shape", 2 a "mesh" (a shape wins)
+ *   dimensions3  "dimensions" of a shape ((1, 1, 1) where absent): a cube's bounds are
+ *                +-dimensions / 2 (lib/src/renderer/systems/vkr_geometry_system.c:588-590)
+ *   material_path  two words per entity: offset and length, in bytes of `json`, of
+ *                the text of a shape's "material" "path" (between the quotes, escapes
+ *                not decoded); 0, 0 for none
+ * Any array may be NULL. A member given as null counts as absent, as in the
+ * reference. VKRHIP_ERR_ARG: not JSON, a parent index out of range or a cycle. */
+typedef struct vkrhip_scene_entities {
+  uint32_t version;          /* "version" of the document (the reference reads 2) */
+  uint32_t entity_count;     /* "entities" */
+  uint32_t renderable_count; /* entities with a shape or a mesh */
+} vkrhip_scene_entities;
+int vkrhip_scene_read_entities(const char *json, uint64_t length, uint32_t capacity,
+                               vkrhip_scene_entities *info, uint32_t *parent, float *pos4, float *quat4,
+                               float *scale4, uint8_t *kind, float *dimensions3,
+                               uint64_t *material_path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_shadow_fit_cascade", "vkrhip_shadow_fit_relevant_caster_z",
     "vkrhip_shadow_quantize_extent_up", "vkrhip_shadow_apply_fit_hysteresis",
     "vkrhip_shadow_build_view_set", "vkrhip_get_caster_bounds", "vkrhip_gltf_read_nodes",
-    "vkrhip_host_alloc", "vkrhip_host_free",
+    "vkrhip_host_alloc", "vkrhip_host_free", "vkrhip_scene_read_entities",
 ]
 
 
@@ -124,6 +124,10 @@ class ShadowSystem(C.Structure):  # vkrhip_shadow_system
 class GltfNodes(C.Structure):  # vkrhip_gltf_nodes
     _fields_ = [("node_count", C.c_uint32), ("scene_count", C.c_uint32), ("scene", C.c_uint32),
                 ("scene_nodes", C.c_uint32)]
+
+
+class SceneEntities(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("entity_count", C.c_uint32), ("renderable_count", C.c_uint32)]
 
 
 class VisibilityStats(C.Structure):
@@ -251,6 +255,8 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_read_transparent_visible.argtypes = [vp, u64, u64, vp]
     L.vkrhip_read_transparent.argtypes = [vp, u64, vp, vp, vp, vp]
     L.vkrhip_read_candidates.argtypes = [vp, u64, u64, vp]
+    L.vkrhip_scene_read_entities.argtypes = [C.c_char_p, u64, u32, C.POINTER(SceneEntities), vp, vp, vp, vp,
+                                             vp, vp, vp]
     L.vkrhip_host_alloc.argtypes = [vp, u64, C.POINTER(C.c_void_p)]
     L.vkrhip_host_free.argtypes = [vp, vp]
     L.vkrhip_read_world_bounds.argtypes = [vp, u64, u64, vp]

@@ -1,5 +1,7 @@
-// vkrhip_gltf.cpp - the node hierarchy of a glTF 2.0 document as the arrays the
-// scene path consumes: per node a parent index, translation / rotation / scale
+// vkrhip_gltf.cpp - the on-disk formats either side of the scene path, as the
+// arrays the path consumes: the entities of the reference's scene files
+// (vkrhip_scene_read_entities, at the end), and the node hierarchy of a glTF 2.0
+// document: per node a parent index, translation / rotation / scale
 // (or a matrix), the mesh it draws, and whether the chosen scene reaches it.
 // The reference imports glTF through cgltf (vendor/cgltf.h, used by its mesh
 // loader); what this path needs of such a file is only "nodes" and "scenes",
@@ -345,6 +347,123 @@ int vkrhip_gltf_read_nodes(const char *json, uint64_t length, uint32_t scene, ui
     if (mesh) mesh[i] = nd.mesh;
     if (has_matrix) has_matrix[i] = nd.has_matrix ? 1 : 0;
     if (matrix16) std::memcpy(matrix16 + 16 * (size_t)i, nd.matrix, sizeof(nd.matrix));
+  }
+  return VKRHIP_OK;
+} catch (...) {
+  return VKRHIP_ERR_ARG;  // out of host memory while parsing
+}
+
+// "entities" of one of the reference's scene files (version 2).
+int vkrhip_scene_read_entities(const char *json, uint64_t length, uint32_t capacity,
+                               vkrhip_scene_entities *info, uint32_t *parent, float *pos4, float *quat4,
+                               float *scale4, uint8_t *kind, float *dimensions3,
+                               uint64_t *material_path) try {
+  if (!json || !info) return VKRHIP_ERR_ARG;
+  std::memset(info, 0, sizeof(*info));
+  struct Entity {
+    uint32_t parent = 0xffffffffu;
+    float pos[3] = {0.f, 0.f, 0.f};
+    float rot[4] = {0.f, 0.f, 0.f, 1.f};
+    float scale[3] = {1.f, 1.f, 1.f};
+    float dims[3] = {1.f, 1.f, 1.f};
+    bool shape = false, mesh = false;
+    uint64_t path_begin = 0, path_length = 0;  // the material path's text inside the document
+  };
+  std::vector<Entity> entities;
+  double version = 0.0;
+  // a member that may be null: true when it was (and has been consumed)
+  auto take_null = [](Cursor &v) {
+    skip_space(v);
+    return v.p < v.end && *v.p == 'n' && skip_literal(v, "null");
+  };
+
+  Cursor c{json, json + length};
+  const bool parsed = parse_object(c, 0, [&](const std::string &key, Cursor &v) {
+    if (key == "version") return parse_number(v, &version);
+    if (key != "entities") return skip_value(v, 1);
+    entities.clear();
+    return parse_array(v, 1, [&](uint32_t, Cursor &ev) {
+      entities.emplace_back();
+      Entity &e = entities.back();
+      return parse_object(ev, 2, [&](const std::string &k, Cursor &mv) {
+        if (k == "parent") {
+          if (take_null(mv)) return true;
+          return parse_index(mv, &e.parent);
+        }
+        if (k == "transform") {
+          if (take_null(mv)) return true;
+          return parse_object(mv, 3, [&](const std::string &tk, Cursor &tv) {
+            if (tk == "pos") return parse_floats(tv, 4, e.pos, 3);
+            if (tk == "rot") return parse_floats(tv, 4, e.rot, 4);
+            if (tk == "scale") return parse_floats(tv, 4, e.scale, 3);
+            return skip_value(tv, 4);
+          });
+        }
+        if (k == "mesh") {
+          if (take_null(mv)) return true;
+          e.mesh = true;
+          return skip_value(mv, 3);
+        }
+        if (k == "shape") {
+          if (take_null(mv)) return true;
+          e.shape = true;
+          return parse_object(mv, 3, [&](const std::string &sk, Cursor &sv) {
+            if (sk == "dimensions") return parse_floats(sv, 4, e.dims, 3);
+            if (sk != "material" || take_null(sv)) return sk == "material" ? true : skip_value(sv, 4);
+            return parse_object(sv, 4, [&](const std::string &pk, Cursor &pv) {
+              if (pk != "path") return skip_value(pv, 5);
+              skip_space(pv);
+              const char *open = pv.p;  // at the opening quote
+              if (!parse_string(pv, nullptr)) return false;
+              e.path_begin = (uint64_t)(open + 1 - json);
+              e.path_length = (uint64_t)(pv.p - 1 - (open + 1));
+              return true;
+            });
+          });
+        }
+        return skip_value(mv, 3);
+      });
+    });
+  });
+  skip_space(c);
+  if (!parsed || c.p != c.end) return VKRHIP_ERR_ARG;  // not a JSON document
+  if (!(version >= 0.0) || version > 4294967295.0) return VKRHIP_ERR_ARG;
+
+  const uint32_t n = (uint32_t)entities.size();
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t p = entities[i].parent;
+    if (p != 0xffffffffu && (p >= n || p == i)) return VKRHIP_ERR_ARG;
+  }
+  for (uint32_t i = 0; i < n; ++i) {  // no cycles
+    uint32_t at = i, steps = 0;
+    while (entities[at].parent != 0xffffffffu) {
+      at = entities[at].parent;
+      if (++steps > n) return VKRHIP_ERR_ARG;
+    }
+  }
+  info->version = (uint32_t)version;
+  info->entity_count = n;
+  for (const Entity &e : entities) info->renderable_count += (e.shape || e.mesh) ? 1u : 0u;
+  if (n > capacity) return VKRHIP_ERR_CAPACITY;  // info tells how much room the arrays need
+
+  for (uint32_t i = 0; i < n; ++i) {
+    const Entity &e = entities[i];
+    if (parent) parent[i] = e.parent;
+    if (pos4) {
+      float *o = pos4 + 4 * (size_t)i;
+      o[0] = e.pos[0], o[1] = e.pos[1], o[2] = e.pos[2], o[3] = 0.f;
+    }
+    if (quat4) std::memcpy(quat4 + 4 * (size_t)i, e.rot, sizeof(e.rot));
+    if (scale4) {
+      float *o = scale4 + 4 * (size_t)i;
+      o[0] = e.scale[0], o[1] = e.scale[1], o[2] = e.scale[2], o[3] = 0.f;
+    }
+    if (kind) kind[i] = e.shape ? 1u : (e.mesh ? 2u : 0u);
+    if (dimensions3) std::memcpy(dimensions3 + 3 * (size_t)i, e.dims, sizeof(e.dims));
+    if (material_path) {
+      material_path[2 * (size_t)i] = e.shape ? e.path_begin : 0u;
+      material_path[2 * (size_t)i + 1] = e.shape ? e.path_length : 0u;
+    }
   }
   return VKRHIP_OK;
 } catch (...) {

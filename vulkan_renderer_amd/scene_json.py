@@ -2,7 +2,9 @@
 restricted to what the scene-processing path consumes: the entity hierarchy,
 TRS transforms and one draw candidate per renderable entity.
 
-Follows scene_loader.c (lib/src/renderer/resources/loaders/scene_loader.c:1230-1460):
+The entity arrays come from the library's reader (vkrhip_scene_read_entities,
+C ABI); this module adds the material files and the candidate rows. Follows
+scene_loader.c (lib/src/renderer/resources/loaders/scene_loader.c:1230-1460):
 `parent` is an index into `entities` or null, `transform` = {pos, rot (x,y,z,w),
 scale}. A `shape` of type cube gets the bounds the geometry system gives a cube
 (centre 0, extents +-dimensions/2; lib/src/renderer/systems/vkr_geometry_system.c:588-590);
@@ -66,51 +68,65 @@ class LoadedScene:
     notes: list = field(default_factory=list)
 
 
+def read_entities(text: bytes) -> dict:
+    """The entity arrays of a scene document through the library
+    (vkrhip_scene_read_entities): parent, TRS, what an entity draws, a shape's
+    dimensions and material path. Raises ValueError for what the library rejects."""
+    import ctypes as C
+    lib = N.load()
+    info = N.SceneEntities()
+    rc = lib.vkrhip_scene_read_entities(text, len(text), 0, C.byref(info), None, None, None, None, None,
+                                        None, None)
+    if rc not in (0, N.ERR_CAPACITY):
+        raise ValueError("not a scene document the library accepts")
+    n = info.entity_count
+    out = {"version": info.version, "parent": np.zeros(n, np.uint32), "pos": np.zeros((n, 4), np.float32),
+           "quat": np.zeros((n, 4), np.float32), "scale": np.zeros((n, 4), np.float32),
+           "kind": np.zeros(n, np.uint8), "dimensions": np.zeros((n, 3), np.float32),
+           "material_path": np.zeros((n, 2), np.uint64), "renderables": info.renderable_count}
+    if n:
+        rc = lib.vkrhip_scene_read_entities(text, len(text), n, C.byref(info), N.ptr(out["parent"]),
+                                            N.ptr(out["pos"]), N.ptr(out["quat"]), N.ptr(out["scale"]),
+                                            N.ptr(out["kind"]), N.ptr(out["dimensions"]),
+                                            N.ptr(out["material_path"]))
+        if rc != 0:
+            raise ValueError("not a scene document the library accepts")
+    return out
+
+
 def load_scene(path: str, material_dir: str | None = None) -> LoadedScene:
     """Parses one scene file. Materials are looked up by file name in
     `material_dir` (default: the scene file's directory); a missing material
     file means an opaque single-sided material and is recorded in `notes`."""
-    with open(path) as fh:
-        doc = json.load(fh)
-    if doc.get("version") != 2:
-        raise ValueError(f"{path}: scene version {doc.get('version')} is not supported")
+    with open(path, "rb") as fh:
+        text = fh.read()
+    ent = read_entities(text)  # the library's reader (C ABI)
+    if ent["version"] != 2:
+        raise ValueError(f"{path}: scene version {ent['version']} is not supported")
     material_dir = material_dir or os.path.dirname(os.path.abspath(path))
-    ents = doc["entities"]
-    n = len(ents)
-    parent = np.full(n, N.NO_PARENT, np.uint32)
-    pos = np.zeros((n, 4), np.float32)
-    quat = np.zeros((n, 4), np.float32)
-    quat[:, 3] = 1.0
-    scale = np.ones((n, 4), np.float32)
-    scale[:, 3] = 0.0
-    rows, notes, names = [], [], []
-    for i, e in enumerate(ents):
-        names.append(e.get("name", f"entity{i}"))
-        if e.get("parent") is not None:
-            p = int(e["parent"])
-            if not 0 <= p < n or p == i:
-                raise ValueError(f"{path}: entity {i} has parent {p}")
-            parent[i] = p
-        t = e.get("transform", {})
-        pos[i, :3] = t.get("pos", [0, 0, 0])
-        quat[i] = t.get("rot", [0, 0, 0, 1])
-        scale[i, :3] = t.get("scale", [1, 1, 1])
-        if "shape" in e:
-            dims = np.asarray(e["shape"].get("dimensions", [1, 1, 1]), np.float32)
-            mat = e["shape"].get("material", {})
-        elif "mesh" in e:
-            dims = np.ones(3, np.float32)
-            mat = {}
-            notes.append(f"{names[-1]}: mesh file not read, unit-cube bounds")
-        else:
+    n = ent["parent"].shape[0]
+    parent, pos, quat, scale = ent["parent"], ent["pos"], ent["quat"], ent["scale"]
+    # names are only used in the notes below
+    names = [e.get("name", f"entity{i}") for i, e in enumerate(json.loads(text)["entities"])]
+    rows, notes = [], []
+    for i in range(n):
+        kind = int(ent["kind"][i])
+        if kind == 0:
             continue
-        mpath = os.path.join(material_dir, os.path.basename(mat.get("path", ""))) if mat else ""
+        offset, length = (int(x) for x in ent["material_path"][i])
+        mat_path = text[offset: offset + length].decode() if length else ""
+        if kind == 1:
+            dims = ent["dimensions"][i]
+        else:
+            dims = np.ones(3, np.float32)
+            notes.append(f"{names[i]}: mesh file not read, unit-cube bounds")
+        mpath = os.path.join(material_dir, os.path.basename(mat_path)) if mat_path else ""
         if mpath and os.path.isfile(mpath):
             m = read_material(mpath)
         else:
             m = {"alpha_mode": "opaque", "double_sided": False, "transmission_factor": 0.0}
-            if mat:
-                notes.append(f"{names[-1]}: material {mat.get('path')} not found, opaque assumed")
+            if mat_path:
+                notes.append(f"{names[i]}: material {mat_path} not found, opaque assumed")
         rows.append((i, dims * np.float32(0.5), material_bits(m)))
     m_rows = len(rows)
     ident = np.zeros((m_rows, 8), np.uint32)
