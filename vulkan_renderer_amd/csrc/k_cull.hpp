@@ -458,14 +458,22 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   // are two compares whose results are masks already
   const unsigned long long gate_mask = __ballot(gate);
   const unsigned long long unbounded_mask = __ballot(!bounds_valid);
+  // (views mostly ask for the same flags as the view before them - every shadow
+  // and probe view for SHADOW_CASTER -, so the lanes that carry a view's flags are
+  // only worked out when the word changes)
+  uint32_t flags_of = ~0u;  // the word carried_mask belongs to (no view asks for every bit)
+  unsigned long long carried_mask = 0ull;
   for (uint32_t v = 0; v < a.views; ++v) {
     const uint32_t req = required[v];
     // evaluated for the whole wave without a branch: the plane loads then issue
     // together with the gate word, ahead of any wait
     const bool inside = sphere_visible(paired + v * 24u, c.x, c.y, c.z, radius);
     if (!TIES && !HZB) {
-      const unsigned long long mp =
-          gate_mask & __ballot((cf & req) == req) & (__ballot(inside) | unbounded_mask);
+      if (req != flags_of) {  // wave-uniform
+        carried_mask = __ballot((cf & req) == req);
+        flags_of = req;
+      }
+      const unsigned long long mp = gate_mask & carried_mask & (__ballot(inside) | unbounded_mask);
       if (leader) s.mask[v * CULL_SLOTS + slot] = mp;
       continue;
     }
