@@ -23,7 +23,7 @@ HIPCC_FLAGS = [
     # written out by hand
     "-fno-slp-vectorize",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-std=c++17",
-    "-Wall", "-Wno-unused-function",
+    "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
 ]
 
 

@@ -463,6 +463,23 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   // only worked out when the word changes)
   uint32_t flags_of = ~0u;  // the word carried_mask belongs to (no view asks for every bit)
   unsigned long long carried_mask = 0ull;
+  // The survivors' ballot of view v is parked in lane v of a register pair (two
+  // lane writes, no branch) and the views' ballots go to the table with one store
+  // behind the loop, lane v writing view v's (views <= 64).
+  uint32_t ballots_lo = 0u, ballots_hi = 0u;
+  auto park = [&](uint32_t v, unsigned long long ballot) {
+    // v_writelane_b32 takes one scalar register besides the lane number, which
+    // therefore travels in M0. M0 is set right here and nothing else in these
+    // kernels reads it (the LDS instructions of this chip do not), so the
+    // compiler's remark that it does not track the register is without effect.
+    // (A select on lane == v instead costs three vector instructions per view:
+    // 64 views 1036 us against 1010 us.)
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(ballots_lo), "+v"(ballots_hi)
+        : "s"((uint32_t)ballot), "s"((uint32_t)(ballot >> 32)), "s"(v)
+        : "m0");
+  };
+  static_assert(CULL_MAX_VIEWS <= 64, "one lane per view");
   for (uint32_t v = 0; v < a.views; ++v) {
     const uint32_t req = required[v];
     // evaluated for the whole wave without a branch: the plane loads then issue
@@ -473,8 +490,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
         carried_mask = __ballot((cf & req) == req);
         flags_of = req;
       }
-      const unsigned long long mp = gate_mask & carried_mask & (__ballot(inside) | unbounded_mask);
-      if (leader) s.mask[v * CULL_SLOTS + slot] = mp;
+      park(v, gate_mask & carried_mask & (__ballot(inside) | unbounded_mask));
       continue;
     }
     bool pass = gate && (cf & req) == req;
@@ -502,9 +518,10 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
       const unsigned long long mocc = __ballot(occluded);
       if (leader && mocc) atomicAdd(&s.stat[4], (uint32_t)__popcll(mocc));
     }
-    const unsigned long long mp = __ballot(pass);
-    if (leader) s.mask[v * CULL_SLOTS + slot] = mp;
+    park(v, __ballot(pass));
   }
+  if (lane_id() < a.views)
+    s.mask[lane_id() * CULL_SLOTS + slot] = ((unsigned long long)ballots_hi << 32) | ballots_lo;
   return (bucket & 0xfu) | (tv ? 0x10u : 0u);
 }
 
