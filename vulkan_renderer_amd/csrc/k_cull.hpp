@@ -467,15 +467,30 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   // lane writes, no branch) and the views' ballots go to the table with one store
   // behind the loop, lane v writing view v's (views <= 64).
   uint32_t ballots_lo = 0u, ballots_hi = 0u;
-  auto park = [&](uint32_t v, unsigned long long ballot) {
-    // v_writelane_b32 takes one scalar register besides the lane number, which
-    // therefore travels in M0. M0 is set right here and nothing else in these
-    // kernels reads it (the LDS instructions of this chip do not), so the
-    // compiler's remark that it does not track the register is without effect.
-    // (A select on lane == v instead costs three vector instructions per view:
-    // 64 views 1036 us against 1010 us.)
+  // v_writelane_b32 takes one scalar register besides the lane number, which
+  // therefore travels in M0. M0 is set right here and nothing else in these
+  // kernels reads it (the LDS instructions of this chip do not), so the
+  // compiler's remark that it does not track the register is without effect.
+  // One hazard the compiler does not cover inside an asm statement:
+  // v_writelane_b32 right behind a VECTOR instruction that wrote its data
+  // register (v_cmp) reads the old value on this chip (measured: wrong in 99.9 %
+  // of cases without wait states, never with four); a register written by a
+  // scalar instruction needs none. park_anded is for ballots that come out of
+  // scalar ANDs (the fast path below: its value is always the result of
+  // s_and_b64); park copies the value with scalar moves first (2 % at 64 views).
+  // (A select on lane == v instead costs three vector instructions per view:
+  // 64 views 1036 us against 1010 us.)
+  auto park_anded = [&](uint32_t v, unsigned long long ballot) {
     asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
         : "+v"(ballots_lo), "+v"(ballots_hi)
+        : "s"((uint32_t)ballot), "s"((uint32_t)(ballot >> 32)), "s"(v)
+        : "m0");
+  };
+  auto park = [&](uint32_t v, unsigned long long ballot) {
+    uint32_t copy_lo, copy_hi;
+    asm("s_mov_b32 %2, %4\n\ts_mov_b32 %3, %5\n\ts_mov_b32 m0, %6\n\t"
+        "v_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(ballots_lo), "+v"(ballots_hi), "=&s"(copy_lo), "=&s"(copy_hi)
         : "s"((uint32_t)ballot), "s"((uint32_t)(ballot >> 32)), "s"(v)
         : "m0");
   };
@@ -490,7 +505,7 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
         carried_mask = __ballot((cf & req) == req);
         flags_of = req;
       }
-      park(v, gate_mask & carried_mask & (__ballot(inside) | unbounded_mask));
+      park_anded(v, gate_mask & carried_mask & (__ballot(inside) | unbounded_mask));
       continue;
     }
     bool pass = gate && (cf & req) == req;
