@@ -438,7 +438,16 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     const unsigned long long mb = __ballot(valid && !bounds_valid);
     const unsigned long long mo = __ballot(valid && (cf & CF_CAMERA_OPAQUE));
     const unsigned long long mx = __ballot(valid && (cf & CF_TRANSMISSIVE));
+    // views: deferred.slang:316-351. The slot's lanes per bucket leave with the
+    // other words of the slot under ONE branch (a branch per word otherwise).
+    const unsigned long long b0 = __ballot(bucket == 0u), b1 = __ballot(bucket == 1u);
+    const unsigned long long b2 = __ballot(bucket == 2u), b3 = __ballot(bucket == 3u);
     if (leader) {
+      unsigned long long *in_bucket = s.inb + slot * 4u;
+      in_bucket[0] = b0;
+      in_bucket[1] = b1;
+      in_bucket[2] = b2;
+      in_bucket[3] = b3;
       s.tmask[slot] = mt;
       if (mb) atomicAdd(&s.stat[0], (uint32_t)__popcll(mb));
       if (mc) atomicAdd(&s.stat[1], (uint32_t)__popcll(mc));
@@ -447,12 +456,6 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     }
   }
 
-  // views: deferred.slang:316-351
-#pragma unroll
-  for (uint32_t q = 0; q < 4u; ++q) {
-    const unsigned long long in_bucket = __ballot(bucket == q);
-    if (leader) s.inb[slot * 4u + q] = in_bucket;
-  }
   const bool gate = valid && bucket < 4u && !(cf & CF_UNPUBLISHED);
   // the view-independent part of the outcome as wave masks: what is left per view
   // are two compares whose results are masks already
