@@ -462,8 +462,8 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   const unsigned long long gate_mask = __ballot(gate);
   const unsigned long long unbounded_mask = __ballot(!bounds_valid);
   // (views mostly ask for the same flags as the view before them - every shadow
-  // and probe view for SHADOW_CASTER -, so the lanes that carry a view's flags are
-  // only worked out when the word changes)
+  // and probe view for SHADOW_CASTER -, so the lanes that pass the gate and carry
+  // a view's flags are only worked out when the word changes)
   uint32_t flags_of = ~0u;  // the word carried_mask belongs to (no view asks for every bit)
   unsigned long long carried_mask = 0ull;
   // The survivors' ballot of view v is parked in lane v of a register pair (two
@@ -478,16 +478,18 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   // v_writelane_b32 right behind a VECTOR instruction that wrote its data
   // register (v_cmp) reads the old value on this chip (measured: wrong in 99.9 %
   // of cases without wait states, never with four); a register written by a
-  // scalar instruction needs none. park_anded is for ballots that come out of
-  // scalar ANDs (the fast path below: its value is always the result of
-  // s_and_b64); park copies the value with scalar moves first (2 % at 64 views).
+  // scalar instruction needs none. So the value is always made by a scalar
+  // instruction INSIDE the statement: the last AND of the fast path's masks
+  // (park_and), or a copy (park).
   // (A select on lane == v instead costs three vector instructions per view:
   // 64 views 1036 us against 1010 us.)
-  auto park_anded = [&](uint32_t v, unsigned long long ballot) {
-    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-        : "+v"(ballots_lo), "+v"(ballots_hi)
-        : "s"((uint32_t)ballot), "s"((uint32_t)(ballot >> 32)), "s"(v)
-        : "m0");
+  auto park_and = [&](uint32_t v, unsigned long long x, unsigned long long y) {
+    uint32_t made_lo, made_hi;
+    asm("s_and_b32 %2, %4, %6\n\ts_and_b32 %3, %5, %7\n\ts_mov_b32 m0, %8\n\t"
+        "v_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(ballots_lo), "+v"(ballots_hi), "=&s"(made_lo), "=&s"(made_hi)
+        : "s"((uint32_t)x), "s"((uint32_t)(x >> 32)), "s"((uint32_t)y), "s"((uint32_t)(y >> 32)), "s"(v)
+        : "m0", "scc");
   };
   auto park = [&](uint32_t v, unsigned long long ballot) {
     uint32_t copy_lo, copy_hi;
@@ -505,10 +507,10 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     const bool inside = sphere_visible(paired + v * 24u, c.x, c.y, c.z, radius);
     if (!TIES && !HZB) {
       if (req != flags_of) {  // wave-uniform
-        carried_mask = __ballot((cf & req) == req);
+        carried_mask = gate_mask & __ballot((cf & req) == req);
         flags_of = req;
       }
-      park_anded(v, gate_mask & carried_mask & (__ballot(inside) | unbounded_mask));
+      park_and(v, carried_mask, __ballot(inside) | unbounded_mask);
       continue;
     }
     bool pass = gate && (cf & req) == req;
