@@ -62,3 +62,15 @@ def assert_bits_equal(a, b, what=""):
         idx = np.argwhere(ne)[:5]
         raise AssertionError(f"{what}: {int(ne.sum())} of {ne.size} floats differ bitwise, first at "
                              f"{idx.tolist()}: {a[tuple(idx[0])]!r} vs {b[tuple(idx[0])]!r}")
+
+
+@pytest.fixture(params=["default", "staged"])
+def staged_mode(request, monkeypatch):
+    """Runs a test twice: as the library decides by itself (small frames leave the
+    expansion of the survivor masks to the gather kernel) and with
+    VKRHIP_STAGED=2, where the classify blocks of every frame the variants exist
+    for expand their own survivors and k_place moves the staged runs (what large
+    frames do by default). The switch is read when a context is created."""
+    if request.param == "staged":
+        monkeypatch.setenv("VKRHIP_STAGED", "2")
+    return request.param

@@ -102,20 +102,20 @@ def test_everything_published(oracle):
     assert counts[0] == 6000 and info.views[0].visible_count > 50
 
 
-def test_publication_boundary_omits_rows(oracle):
+def test_publication_boundary_omits_rows(oracle, staged_mode):
     info, counts = run_case(oracle, 9000, 8192, drop_geometry=0.15, drop_material=0.1,
                             stale_generation=0.05)
     assert counts[1] > 100 and counts[2] > 100 and counts[0] < 9000
 
 
-def test_partition_overflow_and_no_commands(oracle):
+def test_partition_overflow_and_no_commands(oracle, staged_mode):
     info, _ = run_case(oracle, 5000, 64, drop_geometry=0.05)
     assert any(st.overflow_count for st in info.views)
     run_case(oracle, 3000, 0, drop_material=0.2)       # unlimited partitions: no command buffer
 
 
 @pytest.mark.parametrize("list_capacity", [333, 1, 128, 1000])
-def test_list_capacity_below_the_survivors(oracle, list_capacity):
+def test_list_capacity_below_the_survivors(oracle, list_capacity, staged_mode):
     """A per-view list shorter than the survivors (and not a multiple of the encode
     block): the ranges, counts, visible rows and commands all end at the capacity
     and no view reads or writes its neighbour's stretch."""
@@ -131,7 +131,7 @@ def test_invalid_submesh_is_reported(oracle):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VKR_RANDOM_SEEDS", "8"))))
-def test_random_publications(oracle, seed):
+def test_random_publications(oracle, seed, staged_mode):
     """Random sizes, partition capacities, view counts and publication gaps."""
     rng = np.random.default_rng(31000 + seed)
     run_case(oracle, int(rng.choice([1, 64, 1025, 3000, 20000])), int(rng.choice([0, 16, 700, 1 << 15])),

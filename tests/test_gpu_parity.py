@@ -20,7 +20,7 @@ def _synth():
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 255, 256, 257, 1023, 1024, 1025, 5000, 70001])
-def test_flat_single_view(oracle, n):
+def test_flat_single_view(oracle, n, staged_mode):
     synth = _synth()
     sc = synth.flat_scene(n, seed=1, blend_fraction=0.3, no_bounds_fraction=0.02)
     vs = synth.camera_views(far=1200.0)
@@ -32,7 +32,7 @@ def test_flat_single_view(oracle, n):
         compare_frame(hs, ref, sc)
 
 
-def test_deep_hierarchy_five_views(oracle):
+def test_deep_hierarchy_five_views(oracle, staged_mode):
     synth = _synth()
     sc = synth.deep_scene(40000, depth=8, seed=2, fanout=4, roots=5, blend_fraction=0.2,
                           transmissive_fraction=0.05, no_bounds_fraction=0.01)
@@ -67,7 +67,7 @@ def test_sixty_four_views(oracle):
         compare_frame(hs, ref, sc)
 
 
-def test_partition_capacity_overflow(oracle):
+def test_partition_capacity_overflow(oracle, staged_mode):
     synth = _synth()
     sc = synth.flat_scene(30000, seed=3, blend_fraction=0.05)
     vs = synth.camera_views(far=3000.0, fov_deg=100.0)
@@ -106,7 +106,7 @@ def test_node_mapping_and_submeshes(oracle):
         assert_bits_equal(wb[::7], exp, "instance world bounds")
 
 
-def test_source_index_base(oracle):
+def test_source_index_base(oracle, staged_mode):
     synth = _synth()
     sc = synth.flat_scene(9000, seed=6, first=123456, blend_fraction=0.4)
     vs = synth.camera_views(far=1500.0)
@@ -118,7 +118,7 @@ def test_source_index_base(oracle):
         compare_frame(hs, ref, sc)
 
 
-def test_dirty_propagation(oracle):
+def test_dirty_propagation(oracle, staged_mode):
     """Only moved nodes and their descendants are recomputed
     (vkr_scene_system.c:1310-1321)."""
     synth = _synth()
@@ -185,7 +185,7 @@ def test_uploaded_locals_and_unordered_hierarchy(oracle):
         assert_bits_equal(hs.read_world(), world_s[order], "levelized world matrices")
 
 
-def test_edge_values(oracle):
+def test_edge_values(oracle, staged_mode):
     """NaN / zero-scale / behind-camera / equal-depth rows."""
     synth = _synth()
     n = 4096

@@ -30,7 +30,7 @@ def _frame_reference(oracle, sc, state, planes, required, vs, partition_capacity
 # VKR_RANDOM_SEEDS widens the sweep for a soak run and VKR_RANDOM_SCALE multiplies the
 # scene sizes; seeds from 12 on also draw probe views (up to 64 views in all)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_RANDOM_SEEDS", "16"))))
-def test_random_scene_over_frames(oracle, seed):
+def test_random_scene_over_frames(oracle, seed, staged_mode):
     from helpers import compare_frame, hip_scene_for, view_set
     from vulkan_renderer_amd import synth
     rng = np.random.default_rng(1000 + seed)
@@ -82,7 +82,7 @@ STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT, STAGE_CANDIDATES, STAGE_BOUNDS =
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_RANDOM_SEEDS", "16"))))
-def test_random_feature_mix(oracle, seed):
+def test_random_feature_mix(oracle, seed, staged_mode):
     """Random combinations of what selects a kernel variant: identity or arbitrary
     candidate->node mapping, tie counting on or off, world bounds written or not,
     the candidate rows emitted or not, one frame call or the stages split over two,

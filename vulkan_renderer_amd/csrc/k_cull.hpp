@@ -38,6 +38,9 @@ constexpr int CULL_SLOTS = CULL_ROUNDS * (CULL_BLOCK / 64);  // (round, wave) pa
 constexpr int CULL_MAX_VIEWS = 64;
 constexpr int CULL_MAX_ROWS = CULL_MAX_VIEWS * 4 + 1;  // (view,bucket) rows + transparent row
 constexpr int MAT_LDS_STRIDE = 5;  // float4 per staged matrix (80 B: conflict-free b128 reads)
+// Up to this many views a classify block expands its segment's survivors itself
+// (segment_finish_staged) instead of leaving its masks to the gather kernel.
+constexpr uint32_t STAGED_MAX_VIEWS = 8;
 
 // prepared candidate word
 constexpr uint32_t CF_BOUNDS_VALID = 0x1u;    // VKR_WORLD_DRAW_CANDIDATE_BOUNDS_VALID
@@ -182,6 +185,38 @@ struct CullArgs {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Element `index` of an array whose base is the same for the whole wave, addressed
+// as that base (a scalar register pair) plus a 32-bit byte offset per lane: no
+// 64-bit address arithmetic and no 64-bit address registers per lane. The caller
+// guarantees that index * sizeof(T) fits 32 bits.
+template <typename T>
+__device__ __forceinline__ const T *at32(const T *uniform_base, uint32_t index) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(uniform_base) +
+                                     index * (uint32_t)sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ T *at32(T *uniform_base, uint32_t index) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
+}
+
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no
+// LDS round trips): four shifted adds scan each row of 16 lanes, then lane 15 of
+// rows 0 and 2 is added to rows 1 and 3, then lane 31 to rows 2 and 3. A lane
+// whose source lies outside its row, or whose row is masked, receives 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // Sixteen bytes that only pass through registers on their way from global memory
 // to LDS. As the native vector type the copies are one load and one store; as
 // float4 (a struct) the compiler chains block copies through a stack slot.
@@ -221,6 +256,7 @@ struct CullShared {
   uint32_t *ties;
   uint32_t *stat;
   uint32_t *box;  // the block's share of CullArgs::caster_bounds
+  uint16_t *pair;  // [views][64] (views <= STAGED_MAX_VIEWS): see segment_finish_staged
   uint32_t rows;
   uint32_t views;
 };
@@ -229,7 +265,8 @@ struct CullShared {
 __host__ __device__ inline uint32_t seg_record_words(uint32_t views) { return CULL_SLOTS * (views + 5u); }
 
 __host__ __device__ inline size_t cull_shared_words(uint32_t views) {
-  return 2u * (size_t)seg_record_words(views) + views + 5u + 6u;
+  return 2u * (size_t)seg_record_words(views) + views + 5u + 6u +
+         (views <= STAGED_MAX_VIEWS ? views * 32u : 0u);  // 64 16-bit pair bases per view
 }
 // A block may hold the working set more than once (a block that walks several
 // segments alternates between two sets); a set starts on an 8-byte boundary.
@@ -252,6 +289,7 @@ __device__ __forceinline__ CullShared cull_shared_set(uint32_t views, uint32_t w
   s.ties = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
   s.stat = s.ties + views;
   s.box = s.stat + 5;
+  s.pair = reinterpret_cast<uint16_t *>(s.box + 6);
   return s;
 }
 
@@ -284,6 +322,7 @@ __device__ __forceinline__ CullShared cull_shared_init(uint32_t views, uint32_t 
   s.ties = reinterpret_cast<uint32_t *>(s.tmask + CULL_SLOTS);
   s.stat = s.ties + views;
   s.box = s.stat + 5;
+  s.pair = reinterpret_cast<uint16_t *>(s.box + 6);
   // everything starts at zero: slots a block does not run must read as "nobody survives"
   const uint32_t total = (uint32_t)(cull_shared_set_words(views) * sets);
   for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) cull_lds[k] = 0u;
@@ -545,6 +584,42 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
   return (bucket & 0xfu) | (tv ? 0x10u : 0u);
 }
 
+// The block's statistics, tie counts and caster box go to their global accumulators.
+// (Every LDS accumulator is set back to zero by the thread that flushes it: a block
+// that walks several segments uses the set again two segments later.)
+template <bool TIES>
+__device__ __forceinline__ void segment_flush_statistics(const CullArgs &a, CullShared &s) {
+  const uint32_t t = threadIdx.x;
+  if (t == 0) {
+    uint32_t *shard = a.counters + stat_shard();
+    const int which[5] = {CNT_WITHOUT_BOUNDS, CNT_CULLED_CAMERA, CNT_CAMERA_OPAQUE, CNT_TRANSMISSION,
+                          CNT_OCCLUDED};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const uint32_t v = s.stat[k];
+      if (v) {
+        atomicAdd(&shard[which[k]], v);
+        s.stat[k] = 0u;
+      }
+    }
+  }
+  if (TIES)
+    for (uint32_t r = t; r < a.views; r += blockDim.x) {
+      const uint32_t v = s.ties[r];
+      if (v) {
+        atomicAdd(&a.ties[(blockIdx.x % TIE_SHARDS) * CULL_MAX_VIEWS + r], (unsigned long long)v);
+        s.ties[r] = 0u;
+      }
+    }
+  if (a.caster_bounds != nullptr && t < 6u) {
+    const uint32_t v = s.box[t];
+    if (v) {
+      atomicMax(&a.caster_bounds[t], v);
+      s.box[t] = 0u;
+    }
+  }
+}
+
 // Ends a segment: stores the survivor counts of every row (one column of the
 // count table), the segment's record and the statistics. Slot k, lane j of the
 // record is candidate `origin + 64 k + j` (`origin` may lie before the level's
@@ -575,37 +650,8 @@ __device__ __forceinline__ void segment_finish(const CullArgs &a, CullShared &s,
     unsigned long long *record = a.seg_masks + seg * words;
     for (uint32_t k = t; k < words; k += CULL_BLOCK) record[k] = s.mask[k];
   }
-  // (every accumulator is set back to zero by the thread that flushes it: a block
-  // that walks several segments uses the set again two segments later)
-  if (t == 0) {
-    a.seg_first[seg] = origin;
-    uint32_t *shard = a.counters + stat_shard();
-    const int which[5] = {CNT_WITHOUT_BOUNDS, CNT_CULLED_CAMERA, CNT_CAMERA_OPAQUE, CNT_TRANSMISSION,
-                          CNT_OCCLUDED};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const uint32_t v = s.stat[k];
-      if (v) {
-        atomicAdd(&shard[which[k]], v);
-        s.stat[k] = 0u;
-      }
-    }
-  }
-  if (TIES)
-    for (uint32_t r = t; r < a.views; r += blockDim.x) {
-      const uint32_t v = s.ties[r];
-      if (v) {
-        atomicAdd(&a.ties[(blockIdx.x % TIE_SHARDS) * CULL_MAX_VIEWS + r], (unsigned long long)v);
-        s.ties[r] = 0u;
-      }
-    }
-  if (a.caster_bounds != nullptr && t < 6u) {
-    const uint32_t v = s.box[t];
-    if (v) {
-      atomicMax(&a.caster_bounds[t], v);
-      s.box[t] = 0u;
-    }
-  }
+  segment_flush_statistics<TIES>(a, s);
+  if (threadIdx.x == 0) a.seg_first[seg] = origin;
 }
 
 // A segment without candidates still owns a column of the count table and a
@@ -616,6 +662,119 @@ __device__ __forceinline__ void segment_empty(const CullArgs &a, uint64_t seg) {
   const uint32_t words = seg_record_words(a.views);
   unsigned long long *record = a.seg_masks + seg * words;
   for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) record[k] = 0ull;
+  if (threadIdx.x == 0) a.seg_first[seg] = 0u;
+}
+
+// ---------------------------------------------------------------------------
+// Staged compaction (views <= STAGED_MAX_VIEWS). Instead of leaving its masks to
+// the gather kernel, the classify block expands them itself when its segment
+// ends, from LDS, while the other blocks of the CU keep the memory system busy:
+// for every view the segment's survivors go, as 16-bit positions inside the
+// segment, to the segment's own stretch of a staging list - bucket after bucket,
+// ascending candidate inside a bucket, i.e. in the order of the final list. What
+// is left for the launch behind the scan (k_place) is to move runs: where a
+// bucket of a view starts depends on the survivors of ALL segments in the buckets
+// before it (vk_gpu_draw_prefix, deferred.slang:354-377), so no block can know
+// a final position while the classify launch is still running.
+//
+// In this mode CullArgs::seg_masks is one allocation of
+//   [seg_stride][CULL_SLOTS]           64-bit masks of the segments' visible blend rows
+//   [views][seg_stride][CULL_TILE]     16-bit staging lists
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t staged_table_words(uint64_t seg_stride, uint32_t views) {
+  return (size_t)seg_stride * CULL_SLOTS + ((size_t)views * seg_stride * CULL_TILE * sizeof(uint16_t) + 7u) / 8u;
+}
+__host__ __device__ inline uint16_t *staged_lists(unsigned long long *seg_masks, uint64_t seg_stride) {
+  return reinterpret_cast<uint16_t *>(seg_masks + seg_stride * CULL_SLOTS);
+}
+__host__ __device__ inline const uint16_t *staged_lists(const unsigned long long *seg_masks, uint64_t seg_stride) {
+  return reinterpret_cast<const uint16_t *>(seg_masks + seg_stride * CULL_SLOTS);
+}
+
+// A value the whole wave holds alike (read from LDS at a wave-uniform address),
+// as a scalar.
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void segment_finish_staged(const CullArgs &a, CullShared &s, uint64_t seg,
+                                                      uint32_t origin) {
+  static_assert(CULL_SLOTS == 16 && CULL_BLOCK == 256, "lane layouts below");
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  __syncthreads();  // every wave's ballots are in the tables
+  // Wave w takes views w, w + 4, ...: the 64 lanes stand for the view's (bucket,
+  // slot) pairs, bucket-major - the order of the list - so one wave scan of the
+  // pairs' survivor counts gives every pair its place inside the segment's stretch,
+  // and the sums over a bucket's sixteen pairs are the segment's row counts.
+  for (uint32_t v = wave; v < a.views; v += CULL_BLOCK / 64u) {  // wave-uniform
+    const uint32_t slot = lane & 15u, bucket = lane >> 4;
+    const uint32_t count = (uint32_t)__popcll(s.mask[v * CULL_SLOTS + slot] & s.inb[slot * 4u + bucket]);
+    const uint32_t upto = wave_inclusive_scan(count);
+    s.pair[v * 64u + lane] = (uint16_t)(upto - count);
+    const uint32_t before = (uint32_t)__shfl_up((int)upto, 16, 64);  // the buckets before this one
+    if (slot == 15u)
+      a.seg_counts[(uint64_t)(v * 4u + bucket) * a.seg_stride + seg] = upto - (bucket ? before : 0u);
+  }
+  if (wave == (a.views & 3u)) {  // the transparent row; the blend-row masks are what k_place still reads
+    const unsigned long long blend = lane < (uint32_t)CULL_SLOTS ? s.tmask[lane] : 0ull;
+    const uint32_t rows = wave_inclusive_scan((uint32_t)__popcll(blend));
+    if (lane < (uint32_t)CULL_SLOTS) a.seg_masks[seg * CULL_SLOTS + lane] = blend;
+    if (lane == 63u) {
+      a.seg_counts[(uint64_t)(a.views * 4u) * a.seg_stride + seg] = rows;
+      a.seg_first[seg] = origin;
+    }
+  }
+  __syncthreads();  // pair bases
+  // Every wave expands the slots it classified (slot = round * 4 + wave), one lane
+  // per candidate: a survivor's place is its pair's base plus the survivors of the
+  // same bucket below it in the slot. Everything a slot needs from LDS is requested
+  // in one go (clamped indices instead of branches), so that a slot costs one LDS
+  // round trip and not one per view.
+  uint16_t *lists = staged_lists(a.seg_masks, a.seg_stride) + seg * CULL_TILE;
+  const uint64_t list_stride = a.seg_stride * CULL_TILE;
+  const uint32_t bit_lo = lane < 32u ? 1u << lane : 0u;
+  const uint32_t bit_hi = lane < 32u ? 0u : 1u << (lane - 32u);
+  const uint32_t last_view = a.views - 1u;
+#pragma unroll
+  for (uint32_t r = 0; r < (uint32_t)CULL_ROUNDS; ++r) {
+    const uint32_t slot = r * (CULL_BLOCK / 64u) + wave;
+    unsigned long long m[STAGED_MAX_VIEWS];
+#pragma unroll
+    for (uint32_t v = 0; v < STAGED_MAX_VIEWS; ++v) m[v] = s.mask[min(v, last_view) * CULL_SLOTS + slot];
+    const unsigned long long b0 = uniform64(s.inb[slot * 4u + 0u]), b1 = uniform64(s.inb[slot * 4u + 1u]);
+    const unsigned long long b2 = uniform64(s.inb[slot * 4u + 2u]), b3 = uniform64(s.inb[slot * 4u + 3u]);
+    if ((b0 | b1 | b2 | b3) == 0ull) continue;  // wave-uniform: a round the segment did not run
+    auto mine = [&](unsigned long long x) { return (((uint32_t)x & bit_lo) | ((uint32_t)(x >> 32) & bit_hi)) != 0u; };
+    // (a lane in none of the four buckets survives nowhere; what it picks here is never used)
+    const bool in1 = mine(b1), in2 = mine(b2), in3 = mine(b3);
+    const uint32_t bucket = in1 ? 1u : (in2 ? 2u : (in3 ? 3u : 0u));
+    const unsigned long long same = in1 ? b1 : (in2 ? b2 : (in3 ? b3 : b0));
+    const uint32_t same_lo = (uint32_t)same, same_hi = (uint32_t)(same >> 32);
+    uint32_t base[STAGED_MAX_VIEWS];
+#pragma unroll
+    for (uint32_t v = 0; v < STAGED_MAX_VIEWS; ++v) base[v] = s.pair[min(v, last_view) * 64u + bucket * 16u + slot];
+    const uint32_t position = slot * 64u + lane;  // of the candidate inside the segment
+#pragma unroll
+    for (uint32_t v = 0; v < STAGED_MAX_VIEWS; ++v) {
+      if (v >= a.views) break;  // wave-uniform
+      const unsigned long long mv = uniform64(m[v]);
+      if (mv != 0ull && mine(mv)) {
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32) & same_hi,
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mv & same_lo, 0u));
+        *at32(lists + v * list_stride, base[v] + below) = (uint16_t)position;
+      }
+    }
+  }
+  segment_flush_statistics<false>(a, s);
+}
+
+__device__ __forceinline__ void segment_empty_staged(const CullArgs &a, uint64_t seg) {
+  for (uint32_t r = threadIdx.x; r < a.views * 4u + 1u; r += blockDim.x)
+    a.seg_counts[(uint64_t)r * a.seg_stride + seg] = 0u;
+  if (threadIdx.x < (uint32_t)CULL_SLOTS) a.seg_masks[seg * CULL_SLOTS + threadIdx.x] = 0ull;
   if (threadIdx.x == 0) a.seg_first[seg] = 0u;
 }
 
@@ -693,24 +852,6 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_classify(CullArgs a) {
 // Block-wide exclusive scan helpers (1024 threads, 16 waves).
 // ---------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 1024;
-
-// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no
-// LDS round trips): four shifted adds scan each row of 16 lanes, then lane 15 of
-// rows 0 and 2 is added to rows 1 and 3, then lane 31 to rows 2 and 3. A lane
-// whose source lies outside its row, or whose row is masked, receives 0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
-  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
-  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
 
 // Returns the exclusive prefix of `v` over the block and the block total.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave,
@@ -892,7 +1033,8 @@ __device__ __forceinline__ CompactionState prefix_state(const uint32_t *totals4,
 }
 
 struct GatherArgs {
-  const unsigned long long *seg_masks;  // [segment][seg_record_words(views)]
+  const unsigned long long *seg_masks;  // [segment][seg_record_words(views)]; k_place: see segment_finish_staged
+  const uint32_t *seg_counts;   // [row][seg_stride] (k_place only)
   const uint32_t *seg_offsets;  // [row][seg_stride], from k_scan
   const uint32_t *seg_first;
   const uint32_t *row_totals;
@@ -927,6 +1069,71 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, u
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)uniform_src);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)uniform_src);
   return ((unsigned long long)hi << 32) | lo;
+}
+
+// The visible blend rows of SEGS consecutive segments (one wave), one lane per ROW:
+// row j is the j-th set bit of the segments' slot masks (`blend`: lane 16 k + s
+// holds slot s of segment k; candidate order, which is the order of the places),
+// so that everything a row needs - its key and, when the sort runs on a second
+// stream, its world matrix - is requested in one round for all of them.
+// `origin_of(k)`: the candidate of segment k's slot 0, lane 0; `first_of(k)`: the
+// place of segment k's first row.
+template <uint32_t SEGS, typename OriginOf, typename FirstOf>
+__device__ __forceinline__ void gather_blend_rows(const GatherArgs &a, unsigned long long blend,
+                                                  OriginOf origin_of, FirstOf first_of) {
+  static_assert(SEGS == 1u || SEGS == 2u || SEGS == 4u, "one lane per slot mask");
+  constexpr uint32_t MASKS = SEGS * (uint32_t)CULL_SLOTS;
+  const uint32_t lane = lane_id();
+  const uint32_t last_candidate = (uint32_t)(a.candidates - 1u);
+  const uint32_t in_slot = (uint32_t)__popcll(blend);
+  const uint32_t upto = wave_inclusive_scan(in_slot);  // lanes 0..MASKS-1: rows of masks 0..k
+  const uint32_t rows = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+  for (uint32_t j0 = 0; j0 < rows; j0 += 64u) {  // wave-uniform; one trip unless > 64 rows
+    const uint32_t j = j0 + lane;
+    // the mask of row j: how many masks end at or before it (their row counts ascend)
+    uint32_t k = 0u;
+#pragma unroll
+    for (uint32_t step = MASKS / 2u; step != 0u; step >>= 1) {
+      const uint32_t ends = (uint32_t)__shfl((int)upto, (int)(k + step - 1u), 64);
+      if (ends <= j) k += step;
+    }
+    const unsigned long long m = shfl64(blend, k);
+    uint32_t r = j - (uint32_t)__shfl((int)(upto - in_slot), (int)k, 64);  // row j is the r-th set bit of m
+    // the r-th set bit, by halving
+    uint32_t w = (uint32_t)m, bit = 0u;
+    uint32_t c = (uint32_t)__popc(w);
+    if (r >= c) { r -= c; w = (uint32_t)(m >> 32); bit = 32u; }
+    c = (uint32_t)__popc(w & 0xffffu);
+    if (r >= c) { r -= c; w >>= 16; bit += 16u; }
+    c = (uint32_t)__popc(w & 0xffu);
+    if (r >= c) { r -= c; w >>= 8; bit += 8u; }
+    c = (uint32_t)__popc(w & 0xfu);
+    if (r >= c) { r -= c; w >>= 4; bit += 4u; }
+    c = (uint32_t)__popc(w & 0x3u);
+    if (r >= c) { r -= c; w >>= 2; bit += 2u; }
+    if (r >= (w & 1u)) bit += 1u;
+    // rows of the segments before this row's own
+    const uint32_t before = (uint32_t)__shfl((int)(upto - in_slot), (int)(k & ~((uint32_t)CULL_SLOTS - 1u)), 64);
+    const uint64_t pos = (uint64_t)first_of(k / (uint32_t)CULL_SLOTS) + (j - before);
+    if (j < rows && pos < a.transparent_capacity) {
+      const uint32_t candidate =
+          min(origin_of(k / (uint32_t)CULL_SLOTS) + (k % (uint32_t)CULL_SLOTS) * 64u + bit, last_candidate);
+      const uint64_t key = a.tkey[candidate];
+      if (a.tworld) {
+        const uint64_t nd = a.node ? a.node[candidate] : candidate;
+        // (named values, not an array: an array here is given LDS space addressed
+        // through the dispatch packet, a read of host memory in every wave)
+        const float4 c0 = a.world[nd * 4u], c1 = a.world[nd * 4u + 1u];
+        const float4 c2 = a.world[nd * 4u + 2u], c3 = a.world[nd * 4u + 3u];
+        a.tworld[pos * 4u] = c0;
+        a.tworld[pos * 4u + 1u] = c1;
+        a.tworld[pos * 4u + 2u] = c2;
+        a.tworld[pos * 4u + 3u] = c3;
+      }
+      a.keys[pos] = (key & 0xffffffff00000000ull) | pos;
+      a.tsrc[pos] = candidate;
+    }
+  }
 }
 
 // One wave per segment: turns the segment's survivor masks into its stretch of
@@ -983,61 +1190,9 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
     return a.remap ? a.remap[min(candidate, last_candidate)] : (uint32_t)(a.index_base + candidate);
   };
 
-  // The visible blend rows, one lane per ROW: lane j takes the j-th set bit of the
-  // sixteen slot masks (candidate order, which is the order of the places), so
-  // that everything a row needs - its key and, when the sort runs on a second
-  // stream, its world matrix - is requested in one round for the whole segment.
-  {
-    const unsigned long long blend =
-        lane < (uint32_t)CULL_SLOTS ? record[CULL_SLOTS * (a.views + 4u) + lane] : 0ull;  // lane k: slot k
-    const uint32_t in_slot = (uint32_t)__popcll(blend);
-    const uint32_t upto = wave_inclusive_scan(in_slot);  // lanes 0..15: rows of slots 0..k
-    const uint32_t rows = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
-    const uint64_t first = a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg];
-    for (uint32_t j0 = 0; j0 < rows; j0 += 64u) {  // wave-uniform; one trip unless > 64 rows
-      const uint32_t j = j0 + lane;
-      // the slot of row j: how many slots end at or before it (their row counts ascend)
-      uint32_t k = 0u;
-#pragma unroll
-      for (uint32_t step = (uint32_t)CULL_SLOTS / 2u; step != 0u; step >>= 1) {
-        const uint32_t ends = (uint32_t)__shfl((int)upto, (int)(k + step - 1u), 64);
-        if (ends <= j) k += step;
-      }
-      const unsigned long long m = shfl64(blend, k);
-      uint32_t r = j - (uint32_t)__shfl((int)(upto - in_slot), (int)k, 64);  // row j is the r-th set bit of m
-      // the r-th set bit, by halving
-      uint32_t w = (uint32_t)m, bit = 0u;
-      uint32_t c = (uint32_t)__popc(w);
-      if (r >= c) { r -= c; w = (uint32_t)(m >> 32); bit = 32u; }
-      c = (uint32_t)__popc(w & 0xffffu);
-      if (r >= c) { r -= c; w >>= 16; bit += 16u; }
-      c = (uint32_t)__popc(w & 0xffu);
-      if (r >= c) { r -= c; w >>= 8; bit += 8u; }
-      c = (uint32_t)__popc(w & 0xfu);
-      if (r >= c) { r -= c; w >>= 4; bit += 4u; }
-      c = (uint32_t)__popc(w & 0x3u);
-      if (r >= c) { r -= c; w >>= 2; bit += 2u; }
-      if (r >= (w & 1u)) bit += 1u;
-      const uint64_t pos = first + j;
-      if (j < rows && pos < a.transparent_capacity) {
-        const uint32_t candidate = min(origin + k * 64u + bit, last_candidate);
-        const uint64_t key = a.tkey[candidate];
-        if (a.tworld) {
-          const uint64_t nd = a.node ? a.node[candidate] : candidate;
-          // (named values, not an array: an array here is given LDS space addressed
-          // through the dispatch packet, a read of host memory in every wave)
-          const float4 c0 = a.world[nd * 4u], c1 = a.world[nd * 4u + 1u];
-          const float4 c2 = a.world[nd * 4u + 2u], c3 = a.world[nd * 4u + 3u];
-          a.tworld[pos * 4u] = c0;
-          a.tworld[pos * 4u + 1u] = c1;
-          a.tworld[pos * 4u + 2u] = c2;
-          a.tworld[pos * 4u + 3u] = c3;
-        }
-        a.keys[pos] = (key & 0xffffffff00000000ull) | pos;
-        a.tsrc[pos] = candidate;
-      }
-    }
-  }
+  gather_blend_rows<1>(a, lane < (uint32_t)CULL_SLOTS ? record[CULL_SLOTS * (a.views + 4u) + lane] : 0ull,
+                       [&](uint32_t) { return origin; },
+                       [&](uint32_t) { return a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg]; });
 
   for (uint32_t v0 = 0; v0 < a.views; v0 += 4u) {
     const Chunk c = cur;
@@ -1108,6 +1263,184 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
           }
           if (pos < end) list[pos] = source_row(origin + k * 64u + lane);
         }
+      }
+    }
+  }
+}
+
+// What k_place knows about one (segment, view): the entry indices at which the
+// stretch's buckets end, and per bucket the distance from an entry's index to its
+// place in the view's list and the end of what the list keeps of the bucket.
+struct PlaceRun {
+  uint32_t *list;
+  const uint32_t *remap;
+  uint32_t entries, end0, end1, end2;
+  uint32_t shift0, shift1, shift2, shift3;
+  uint32_t stop0, stop1, stop2, stop3;
+  uint32_t first_row;  // source row of the segment's position 0 without a publication
+  uint32_t origin, last_candidate;
+};
+// Entry e of the stretch (the low 16 bits of `position`: the candidate's place
+// inside its segment) goes to its bucket's run in the view's list.
+// (The run is taken BY VALUE: selects between fields reached through a reference are
+// turned into a load from a selected address, which keeps the whole struct - and
+// with it everything it was filled from - in scratch memory.)
+__device__ __forceinline__ void place_entry(const PlaceRun r, uint32_t e, uint32_t position) {
+  const bool in0 = e < r.end0, in1 = e < r.end1, in2 = e < r.end2;
+  const uint32_t at = e + (in0 ? r.shift0 : (in1 ? r.shift1 : (in2 ? r.shift2 : r.shift3)));
+  const uint32_t stop = in0 ? r.stop0 : (in1 ? r.stop1 : (in2 ? r.stop2 : r.stop3));
+  if (e < r.entries && at < stop) {
+    position &= 0xffffu;
+    r.list[at] = r.remap ? r.remap[min(r.origin + position, r.last_candidate)] : r.first_row + position;
+  }
+}
+
+// The launch behind the scan when the classify blocks staged their survivors
+// themselves (segment_finish_staged): moves every segment's staged runs - per view
+// four, one per state bucket, back to back - to where the scanned offsets and the
+// bucket totals of the whole frame put them, one lane per entry, and turns the
+// 16-bit positions into source rows on the way. A wave takes PLACE_SEGS
+// consecutive segments and requests everything that does not depend on a loaded
+// value - the tables of all of them and the first 64 staged entries of every
+// (segment, view) - in one go: the kernel is bound by the memory round trips a
+// wave makes one after the other (three here, whatever the scene), not by bytes
+// or instructions. views <= STAGED_MAX_VIEWS, so one lane per count row holds
+// everything the wave needs of a segment's tables.
+constexpr uint32_t PLACE_SEGS = 4;
+__global__ __launch_bounds__(GATHER_BLOCK) void k_place(GatherArgs a) {
+  static_assert(STAGED_MAX_VIEWS * 4u + 1u <= 64u, "one lane per count row");
+  static_assert(PLACE_SEGS * CULL_SLOTS <= 64u, "one lane per blend-row mask");
+  // the first 64 staged entries of every (segment, view) of the block's waves
+  __shared__ uint16_t s_head[GATHER_BLOCK / 64][PLACE_SEGS][STAGED_MAX_VIEWS][64];
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = t >> 6;
+  const uint32_t vrows = a.views * 4u;
+  if (blockIdx.x == 0)
+    for (uint32_t v = t; v < a.views; v += GATHER_BLOCK)
+      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity, a.visible_stride);
+
+  // Wave w of W takes segments w, w + W, w + 2 W, ...: neighbouring segments are
+  // neighbours in space and tend to be dense in a view together, and a dense
+  // segment is ten times the work of a sparse one.
+  const uint64_t waves = (a.segments + PLACE_SEGS - 1u) / PLACE_SEGS;
+  const uint64_t seg0 = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
+  if (seg0 >= waves) return;  // wave-uniform; no block-wide barrier below
+  // segments of this wave (the last ones lack where the count is no multiple)
+  const uint32_t held = (uint32_t)((a.segments - seg0 + waves - 1u) / waves);
+  // lane j: count row j (lanes beyond the rows repeat the transparent row)
+  const uint32_t row = min(lane, vrows);
+  const uint16_t *lists = staged_lists(a.seg_masks, a.seg_stride);
+  const uint64_t list_stride = a.seg_stride * CULL_TILE;
+  const uint32_t last_view = a.views - 1u;
+  uint32_t offset[PLACE_SEGS], count[PLACE_SEGS], origin[PLACE_SEGS];
+  {
+    uint32_t head[PLACE_SEGS][STAGED_MAX_VIEWS];
+#pragma unroll
+    for (uint32_t k = 0; k < PLACE_SEGS; ++k) {
+      const uint64_t sk = seg0 + min(k, held - 1u) * waves;
+      offset[k] = a.seg_offsets[(uint64_t)row * a.seg_stride + sk];
+      count[k] = a.seg_counts[(uint64_t)row * a.seg_stride + sk];
+      origin[k] = a.seg_first[sk];
+#pragma unroll
+      for (uint32_t v = 0; v < STAGED_MAX_VIEWS; ++v)
+        head[k][v] = *at32(lists + min(v, last_view) * list_stride + sk * CULL_TILE, lane);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PLACE_SEGS; ++k)
+#pragma unroll
+      for (uint32_t v = 0; v < STAGED_MAX_VIEWS; ++v) s_head[wave][k][v][lane] = (uint16_t)head[k][v];
+  }
+  const unsigned long long blend =
+      lane / (uint32_t)CULL_SLOTS < held
+          ? a.seg_masks[(seg0 + lane / (uint32_t)CULL_SLOTS * waves) * CULL_SLOTS + lane % (uint32_t)CULL_SLOTS]
+          : 0ull;
+  const uint32_t view_row = min(row, vrows - 1u) & ~3u;
+  const uint32_t total0 = a.row_totals[view_row], total1 = a.row_totals[view_row + 1u];
+  const uint32_t total2 = a.row_totals[view_row + 2u], total3 = a.row_totals[view_row + 3u];
+  const uint32_t last_candidate = (uint32_t)(a.candidates - 1u);
+
+  {
+    // (separate values, captured by value: a select over the elements of an array is
+    // turned into an indexed load, which puts the array into scratch memory)
+    const uint32_t o0 = origin[0], o1 = origin[1], o2 = origin[2], o3 = origin[3];
+    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)offset[0], 63);
+    const uint32_t f1 = (uint32_t)__builtin_amdgcn_readlane((int)offset[1], 63);
+    const uint32_t f2 = (uint32_t)__builtin_amdgcn_readlane((int)offset[2], 63);
+    const uint32_t f3 = (uint32_t)__builtin_amdgcn_readlane((int)offset[3], 63);
+    gather_blend_rows<PLACE_SEGS>(
+        a, blend, [o0, o1, o2, o3](uint32_t k) { return k == 0u ? o0 : (k == 1u ? o1 : (k == 2u ? o2 : o3)); },
+        [f0, f1, f2, f3](uint32_t k) { return k == 0u ? f0 : (k == 1u ? f1 : (k == 2u ? f2 : f3)); });
+  }
+
+  // where the row's bucket starts inside its view's list and how much of it is
+  // kept (as prefix_state lays the buckets out)
+  uint32_t row_start = 0u, row_kept = 0u;
+  {
+    const uint32_t b = row & 3u;
+    const uint32_t room0 = bucket_room(total0, a.partition_capacity, a.visible_stride, 0u);
+    const uint32_t room1 = bucket_room(total1, a.partition_capacity, a.visible_stride, room0);
+    const uint32_t room2 = bucket_room(total2, a.partition_capacity, a.visible_stride, room0 + room1);
+    const uint32_t room3 = bucket_room(total3, a.partition_capacity, a.visible_stride, room0 + room1 + room2);
+    row_kept = b == 0u ? room0 : (b == 1u ? room1 : (b == 2u ? room2 : room3));
+    row_start = b == 0u ? 0u : (b == 1u ? room0 : (b == 2u ? room0 + room1 : room0 + room1 + room2));
+  }
+  __builtin_amdgcn_wave_barrier();  // s_head is only read by the wave that wrote it
+  for (uint32_t v = 0; v < a.views; ++v) {  // wave-uniform
+    const uint16_t *staged = lists + v * list_stride;
+    uint32_t *list = a.visible + (uint64_t)v * a.visible_stride;
+    const uint32_t r = v * 4u;
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)row_start, (int)r);
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)row_start, (int)(r + 1u));
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)row_start, (int)(r + 2u));
+    const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)row_start, (int)(r + 3u));
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)row_kept, (int)r);
+    const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)row_kept, (int)(r + 1u));
+    const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)row_kept, (int)(r + 2u));
+    const uint32_t k3 = (uint32_t)__builtin_amdgcn_readlane((int)row_kept, (int)(r + 3u));
+    // The view's runs of all segments of the wave. What lies beyond the first 64
+    // entries of a stretch is requested for ALL of them before any entry is placed,
+    // 64 consecutive entries per load (lane = entry, so that the stores behind them
+    // fall on consecutive words): one more round trip per view, not per stretch.
+    PlaceRun run[PLACE_SEGS];
+    uint32_t more[PLACE_SEGS][CULL_TILE / 64 - 1];
+#pragma unroll
+    for (uint32_t k = 0; k < PLACE_SEGS; ++k) {
+      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)count[k], (int)r);
+      const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)count[k], (int)(r + 1u));
+      const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)count[k], (int)(r + 2u));
+      const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)count[k], (int)(r + 3u));
+      PlaceRun &n = run[k];
+      n.list = list;
+      n.remap = a.remap;
+      n.entries = k < held ? c0 + c1 + c2 + c3 : 0u;  // <= CULL_TILE
+      n.end0 = c0, n.end1 = c0 + c1, n.end2 = c0 + c1 + c2;
+      // per bucket: (its start in the view's list + the segment's scanned offset in it)
+      // minus the entry index at which the bucket starts in the stretch, and the end
+      // of what the list keeps of the bucket
+      n.shift0 = s0 + (uint32_t)__builtin_amdgcn_readlane((int)offset[k], (int)r);
+      n.shift1 = s1 + (uint32_t)__builtin_amdgcn_readlane((int)offset[k], (int)(r + 1u)) - n.end0;
+      n.shift2 = s2 + (uint32_t)__builtin_amdgcn_readlane((int)offset[k], (int)(r + 2u)) - n.end1;
+      n.shift3 = s3 + (uint32_t)__builtin_amdgcn_readlane((int)offset[k], (int)(r + 3u)) - n.end2;
+      n.stop0 = s0 + k0, n.stop1 = s1 + k1, n.stop2 = s2 + k2, n.stop3 = s3 + k3;
+      n.first_row = (uint32_t)a.index_base + origin[k];
+      n.origin = origin[k];
+      n.last_candidate = last_candidate;
+#pragma unroll
+      for (uint32_t j = 1; j < (uint32_t)CULL_TILE / 64u; ++j) {
+        more[k][j - 1u] = 0u;
+        if (n.entries > 64u * j)  // wave-uniform
+          more[k][j - 1u] = *at32(staged + (seg0 + min(k, held - 1u) * waves) * CULL_TILE, 64u * j + lane);
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PLACE_SEGS; ++k) {
+      if (run[k].entries == 0u) continue;  // wave-uniform
+      place_entry(run[k], lane, s_head[wave][k][v][lane]);
+#pragma unroll
+      for (uint32_t j = 1; j < (uint32_t)CULL_TILE / 64u; ++j) {
+        if (run[k].entries <= 64u * j) break;  // wave-uniform
+        place_entry(run[k], 64u * j + lane, more[k][j - 1u]);
       }
     }
   }

@@ -82,20 +82,6 @@ __device__ __forceinline__ uint32_t sub_slot(int r) {
 }
 
 
-// Element `index` of an array whose base is the same for the whole wave, addressed
-// as that base (a scalar register pair) plus a 32-bit byte offset per lane: no
-// 64-bit address arithmetic and no 64-bit address registers per lane. The caller
-// guarantees that index * sizeof(T) fits 32 bits.
-template <typename T>
-__device__ __forceinline__ const T *at32(const T *uniform_base, uint32_t index) {
-  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(uniform_base) +
-                                     index * (uint32_t)sizeof(T));
-}
-template <typename T>
-__device__ __forceinline__ T *at32(T *uniform_base, uint32_t index) {
-  return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
-}
-
 // What one thread loads for one round, in two dependent steps: the head (flags,
 // parent index, cull inputs of its own node) depends on nothing; the matrix
 // columns are picked by the flags of the head. Both steps are unconditional
@@ -346,14 +332,16 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
 // when many views make the classification the longer part of a round; without
 // the cull phase it needs 71 registers and fits six (8M roots: 197 -> 193 us).
 constexpr int fused_waves(bool has_parent, bool cull) { return has_parent ? 4 : (cull ? 5 : 6); }
+// STAGED: the block expands its segment's survivors itself (segment_finish_staged).
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
-          bool STREAM = false>
+          bool STREAM = false, bool STAGED = false>
 __global__ __launch_bounds__(FUSED_BLOCK)
     __attribute__((amdgpu_waves_per_eu(fused_waves(HAS_PARENT, CULL), fused_waves(HAS_PARENT, CULL)))) void
 k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ float4 s_par[HAS_PARENT && !TOP ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns
   static_assert(!TOP || HAS_PARENT, "the merged top levels hold nodes with parents");
+  static_assert(!STAGED || (CULL && !TIES), "staged compaction: cull variants without tie counting");
   __shared__ uint32_t s_updated;
   static_assert(F_DIRTY_LOCAL == 1 && F_DIRTY_WORLD == 2, "flag arithmetic above");
   static_assert((F_DIRTY_LOCAL | F_DIRTY_WORLD | F_WORLD_UPDATED) < F_HAS_PARENT, "marker bit is free");
@@ -385,7 +373,10 @@ k_propagate_classify(FusedArgs a) {
   }
   const uint64_t seg = (uint64_t)a.seg_base + blockIdx.x;  // block order is candidate order
   if (lo >= hi) {  // block-uniform
-    if (CULL) segment_empty(a.c, seg);
+    if (CULL) {
+      if (STAGED) segment_empty_staged(a.c, seg);
+      else segment_empty(a.c, seg);
+    }
     return;
   }
   if (t == 0) s_updated = 0u;
@@ -619,7 +610,10 @@ k_propagate_classify(FusedArgs a) {
     classify_candidate<TIES, BOUNDS_OUT>(a.c, s, (uint32_t)round, base + t, cvalid, world,
                                          make_float4(hd.ls.x, hd.ls.y, hd.ls.z, hd.ls.w), cf);
   }
-  if (CULL) segment_finish<TIES>(a.c, s, seg, (uint32_t)tile_base);
+  if (CULL) {
+    if (STAGED) segment_finish_staged(a.c, s, seg, (uint32_t)tile_base);
+    else segment_finish<TIES>(a.c, s, seg, (uint32_t)tile_base);
+  }
   {
     const uint32_t wave_updates = wave_inclusive_scan(updated_here);
     if ((t & 63u) == 63u && wave_updates) atomicAdd(&s_updated, wave_updates);

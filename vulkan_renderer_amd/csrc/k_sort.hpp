@@ -291,13 +291,14 @@ __device__ __forceinline__ unsigned long long sort_status(uint32_t serial, uint3
 // and walks them in 8 steps of 64 consecutive keys, so (wave, step, lane) order
 // is memory order.
 //
-// Block b starts with tile b and takes further tiles (a grid smaller than the
-// tile count) from the ticket counter, which hands out gridDim.x, gridDim.x + 1,
-// ...: the keys of the first tile, the count and the digit totals are requested
-// together when the block starts, without a ticket's round trip in front of
-// them. A tile's look-back only ever waits for lower tiles: those belong to
-// lower blocks of the grid or to earlier tickets, and the host never launches
-// more blocks than the device holds at once, so all of them are running.
+// Every tile, the first one of a block included, is handed out by the ticket
+// counter: a tile's look-back only waits for lower tiles, i.e. for tickets taken
+// earlier, i.e. for blocks that are already running - whatever share of the grid
+// the device holds at once (beside the next frame's transform, on the second
+// stream, that is often a handful of blocks, and the blocks of a grid are not
+// promised to start in index order). The keys a block requests before it knows
+// its tile are those of tile blockIdx.x, which is the tile it gets when the
+// blocks start in order; otherwise it requests its tile's keys again.
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
   __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave digit counts, then bases
   __shared__ uint32_t s_wave[SORT_BLOCK / 64];
@@ -313,17 +314,21 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) key[k] = a.keys_in[min(wbase + (uint32_t)k * 64u + lane, last)];
   }
+  if (t == 0) s_tile = atomicAdd(&a.state->ticket[a.pass], 1u);
   const uint32_t my_total = a.state->hist[a.pass][t];
   const uint32_t count = a.counters[CNT_TRANSPARENT];
   const uint32_t tiles = (count + SORT_TILE - 1) / SORT_TILE;
-  if (blockIdx.x >= tiles) return;  // block-uniform: the grid covers an estimate of the count
   for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
+  __syncthreads();
+  const uint32_t first_tile = s_tile;
+  if (first_tile >= tiles) return;  // block-uniform: the grid covers an estimate of the count
   // keys with smaller digits come first: exclusive scan of the digit totals
   uint32_t all_keys;
   const uint32_t digit_base = block_exclusive_scan(my_total, s_wave, &all_keys);
   unsigned long long *status = a.status + (size_t)a.pass * a.tiles_stride * SORT_RADIX;
 
-  for (uint32_t tile = blockIdx.x;;) {
+  bool requested = first_tile == blockIdx.x;  // key[] holds the tile's keys already
+  for (uint32_t tile = first_tile;;) {
     bool valid[SORT_ITEMS];
     uint32_t rank[SORT_ITEMS];
     const uint32_t wbase = tile * SORT_TILE + wave * SORT_WAVE_KEYS;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
     for (int k = 0; k < SORT_ITEMS; ++k) {
       const uint32_t idx = wbase + (uint32_t)k * 64u + lane;
       valid[k] = idx < count;
-      if (tile != blockIdx.x) key[k] = a.keys_in[min(idx, last)];  // block-uniform
+      if (!requested) key[k] = a.keys_in[min(idx, last)];  // block-uniform
       if (!valid[k]) key[k] = 0ull;
     }
     wave_rank<SORT_ITEMS>(key, valid, SORT_ITEMS, shift, s_whist[wave], rank);
@@ -415,9 +420,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
         a.keys_out[a.descending ? all_keys - 1u - pos : pos] = key[k];
       }
     }
-    if (tiles <= gridDim.x) break;  // block-uniform: every tile had a block of its own
+    if (tiles <= gridDim.x) break;  // block-uniform: every block takes one ticket before any takes a second
+    requested = false;
     __syncthreads();                // the tile's readers are done with the tables
-    if (t == 0) s_tile = gridDim.x + atomicAdd(&a.state->ticket[a.pass], 1u);
+    if (t == 0) s_tile = atomicAdd(&a.state->ticket[a.pass], 1u);
     for (int w = 0; w < 4; ++w) s_whist[w][t] = 0u;
     __syncthreads();
     tile = s_tile;

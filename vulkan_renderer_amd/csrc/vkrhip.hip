@@ -126,6 +126,11 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> seg_first;    // [seg_stride]
   uint64_t seg_stride = 0;
   uint64_t segments = 0;  // segments of the frame being enqueued
+  // Whether the classify blocks of the fused kernel expand their own survivors
+  // (segment_finish_staged, k_place). VKRHIP_STAGED: 0 never, 1 flat scenes of at
+  // least kStagedMinSegments segments (default), 2 every frame the variants exist for.
+  int staged_compaction = 1;
+  bool frame_staged = false;      // the frame's classify blocks staged their survivors (k_place follows)
   // Per-frame counters: two blocks of [sharded counters | tie counters]. Frames
   // alternate between them; the scan kernel of a frame zeroes the other block,
   // so steady-state frames start without a fill. block_clean falls back to a
@@ -182,6 +187,7 @@ struct vkrhip_ctx {
   DevBuf<unsigned long long> sort_status;  // look-back words of the radix passes
   uint32_t sort_tiles_stride = 0;
   uint32_t sort_serial = 0;  // tags the status words of one sort (never 0)
+  uint32_t sort_block = 0;   // counter block of the last radix sort (its stall flag lives there)
   DevBuf<uint4> draws;
   DevBuf<float4> instances;
 
@@ -631,6 +637,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   if (const char *env = std::getenv("VKRHIP_TOP_BALANCE")) c->top_balance = std::atoi(env) != 0;
   if (const char *env = std::getenv("VKRHIP_STREAMING")) c->streaming_mode = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
+  if (const char *env = std::getenv("VKRHIP_STAGED")) c->staged_compaction = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
@@ -641,8 +648,8 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
       c->cu_count = cus > 0 ? (uint32_t)cus : 0u;
     }
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->tstream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
     const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
@@ -1265,6 +1272,7 @@ static CullArgs cull_args(vkrhip_ctx *c) {
 
 static uint64_t fused_level_grid(const vkrhip_ctx *c, uint32_t l, uint32_t *rounds);
 static bool frame_streams(const vkrhip_ctx *c);
+constexpr uint64_t kStagedMinSegments = 4096;  // see launch_fused
 
 // The merged launch of the top levels: ancestor tables, dynamic LDS behind the
 // cull tables.
@@ -1339,7 +1347,14 @@ static int ensure_segments(vkrhip_ctx *c, uint64_t segments) {
   TRY(dev_alloc(c, c->seg_counts, rows * stride));
   TRY(dev_alloc(c, c->seg_offsets, rows * stride));
   TRY(dev_alloc(c, c->seg_first, stride));
-  TRY(dev_alloc(c, c->seg_masks, stride * seg_record_words(c->cfg.max_views)));
+  // (large enough for either use: the segments' records, or the blend-row masks and
+  // the staging lists of segment_finish_staged)
+  const uint64_t kept = stride & ~(uint64_t)3u;
+  TRY(dev_alloc(c, c->seg_masks,
+                std::max<size_t>(stride * seg_record_words(c->cfg.max_views),
+                                 c->staged_compaction
+                                     ? staged_table_words(kept, std::min<uint32_t>(c->cfg.max_views, STAGED_MAX_VIEWS))
+                                     : 0u)));
   HIP_TRY(c, hipMemsetAsync(c->seg_masks.p, 0, c->seg_masks.count * sizeof(unsigned long long), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->seg_first.p, 0, c->seg_first.count * sizeof(uint32_t), c->stream));
   c->seg_stride = stride & ~(uint64_t)3u;
@@ -1372,6 +1387,11 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
   const dim3 g(grid), b(FUSED_BLOCK);
   const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c)
                          : cull_shared_bytes(a.c.views);
+  if (c->frame_staged) {  // (never with tie counting or world bounds)
+    launch_timed(c, VKRHIP_TIMER_FUSED, first,
+                 k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, true>, g, b, lds, a);
+    return;
+  }
   if (ties) {
     if (bounds_out)
       launch_timed(c, VKRHIP_TIMER_FUSED, first, k_propagate_classify<HAS_PARENT, true, true, true, TOP, STREAM>, g, b, lds, a);
@@ -1395,9 +1415,26 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     uint32_t rounds = 4;
     segments += fused_level_grid(c, l, &rounds);
   }
+  const bool ties = c->cfg.tie_epsilon > 0.f;
+  // the blocks expand their own survivors where that is built: the plain cull
+  // variants, up to STAGED_MAX_VIEWS views
+  // By default only large flat scenes do it. Measured on one box (frame, fused kernel,
+  // compaction behind it; gather / staged): 32M roots with 1, 2, 3 views 1010 / 977,
+  // 1027 / 990, 1026 / 993 us - the root-level variant of the kernel even runs
+  // faster with the expansion at its blocks' end than with the stores of the
+  // segment records (912 / 895 us), and k_place takes 24 us where k_gather takes
+  // 35; a 16M-node hierarchy with 1, 2, 5 views 560 / 570, 583 / 596, 599 / 622 us -
+  // the below-root variant (128 registers, four waves per SIMD) pays 5 to 19 us for
+  // it and k_place is no shorter than k_gather there (59 / 53 us at 5 views: its
+  // waves are few and long). A frame of few segments is one resident set of blocks
+  // or less: the expansion then lengthens the launch by its full duration (1M
+  // roots: 42.5 / 47.3 us).
+  const bool flat = levels == 1u || !c->parent.p;
+  c->frame_staged = !ties && !bounds_out && c->views <= STAGED_MAX_VIEWS &&
+                    (c->staged_compaction >= 2 ||
+                     (c->staged_compaction == 1 && flat && segments >= kStagedMinSegments));
   TRY(ensure_segments(c, segments));
   bool first = true;
-  const bool ties = c->cfg.tie_epsilon > 0.f;
   uint64_t seg_base = 0;
   if (l0) {
     FusedArgs a{};
@@ -1486,6 +1523,7 @@ static void launch_classify_variant(vkrhip_ctx *c, const CullArgs &a, unsigned g
 }
 
 static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
+  c->frame_staged = false;
   c->segments = ceil_div(c->n_cand, CULL_TILE);
   if (!c->n_cand) return VKRHIP_OK;
   TRY(ensure_segments(c, c->segments));
@@ -1527,6 +1565,7 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside) {
     StageTimer timer(c, VKRHIP_TIMER_SCATTER);
     GatherArgs g{};
     g.seg_masks = c->seg_masks.p;
+    g.seg_counts = c->seg_counts.p;
     g.seg_offsets = c->seg_offsets.p;
     g.seg_first = c->seg_first.p;
     g.row_totals = c->row_totals.p;
@@ -1547,8 +1586,9 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside) {
     g.candidates = c->n_cand;
     g.views = c->views;
     g.partition_capacity = c->cfg.partition_capacity;
-    const unsigned grid = (unsigned)ceil_div(segments, GATHER_BLOCK / 64);
-    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(GATHER_BLOCK), 0, c->stream, g);
+    // (a wave of k_gather takes one segment, a wave of k_place PLACE_SEGS)
+    const unsigned grid = (unsigned)ceil_div(segments, (GATHER_BLOCK / 64) * (c->frame_staged ? PLACE_SEGS : 1u));
+    hipLaunchKernelGGL(c->frame_staged ? k_place : k_gather, dim3(grid), dim3(GATHER_BLOCK), 0, c->stream, g);
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
@@ -1622,6 +1662,7 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
       if (++c->sort_serial == 0u) c->sort_serial = 1u;
       SortArgs s{};
       s.state = c->sort_state();
+      c->sort_block = c->cur_block;
       s.status = c->sort_status.p;
       s.counters = c->counters();
       s.tiles_stride = c->sort_tiles_stride;
@@ -1721,8 +1762,13 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     // this frame's counter block is normally already zero (cleared by the
     // previous frame's scan kernel)
     c->cur_block ^= 1u;
-    if (!c->block_clean[c->cur_block])
+    if (!c->block_clean[c->cur_block]) {
+      // the block was last used two frames ago, and that frame's sort and emission
+      // (side stream) read its count, histograms and tickets: they must be done
+      // before it is zeroed (a frame that culls joins anyway, behind its classify)
+      TRY(join_side(c));
       HIP_TRY(c, hipMemsetAsync(c->counter_block(c->cur_block), 0, vkrhip_ctx::kBlockBytes, c->stream));
+    }
     c->block_clean[c->cur_block] = false;
     // the fused kernel serves scenes that draw node i with candidate i
     // (the occlusion test lives in the stand-alone classify kernel only)
@@ -1775,8 +1821,10 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
     HIP_TRY(c, hipMemcpyAsync(tie_shards.data(), c->ties(), tie_shards.size() * 8,
                               hipMemcpyDeviceToHost, c->stream));
   uint32_t sort_stalled = 0;
+  // (the block the last radix sort ran in: a later frame without a sort has moved on)
   HIP_TRY(c, hipMemcpyAsync(&sort_stalled,
-                            reinterpret_cast<const char *>(c->sort_state()) + offsetof(SortState, stalled),
+                            c->counter_block(c->sort_block) + vkrhip_ctx::kCountersBytes +
+                                vkrhip_ctx::kTiesBytes + offsetof(SortState, stalled),
                             4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (sort_stalled)
