@@ -74,3 +74,15 @@ def staged_mode(request, monkeypatch):
     if request.param == "staged":
         monkeypatch.setenv("VKRHIP_STAGED", "2")
     return request.param
+
+
+@pytest.fixture(params=["default", "tail"])
+def tail_mode(request, monkeypatch):
+    """Runs a test twice: as the library decides by itself (small scenes keep the
+    whole frame on one stream) and with VKRHIP_OVERLAP_TAIL=2, where every frame the
+    fused kernel serves puts scan, gather, sort and emission on the second stream
+    and the next frame starts right behind the classify (what large hierarchies do
+    by default). The switch is read when a context is created."""
+    if request.param == "tail":
+        monkeypatch.setenv("VKRHIP_OVERLAP_TAIL", "2")
+    return request.param

@@ -32,7 +32,7 @@ def test_flat_single_view(oracle, n, staged_mode):
         compare_frame(hs, ref, sc)
 
 
-def test_deep_hierarchy_five_views(oracle, staged_mode):
+def test_deep_hierarchy_five_views(oracle, staged_mode, tail_mode):
     synth = _synth()
     sc = synth.deep_scene(40000, depth=8, seed=2, fanout=4, roots=5, blend_fraction=0.2,
                           transmissive_fraction=0.05, no_bounds_fraction=0.01)
@@ -118,7 +118,7 @@ def test_source_index_base(oracle, staged_mode):
         compare_frame(hs, ref, sc)
 
 
-def test_dirty_propagation(oracle, staged_mode):
+def test_dirty_propagation(oracle, staged_mode, tail_mode):
     """Only moved nodes and their descendants are recomputed
     (vkr_scene_system.c:1310-1321)."""
     synth = _synth()
@@ -584,12 +584,15 @@ def test_page_locked_host_buffers(oracle):
         assert hs.lib.vkrhip_host_free(hs.ctx, None) == 0
 
 
-@pytest.mark.parametrize("overlap", ["0", "2"])
+@pytest.mark.parametrize("overlap", ["0", "2", "tail"])
 @pytest.mark.parametrize("blend_fraction", [0.02, 0.6])
 def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_fraction):
     """VKRHIP_OVERLAP_SORT=2: the transparent sort and emission of every frame run on
     a second stream beside the next frame's transform (by default only large
-    hierarchies do that); =0 keeps them on the frame's stream. Frames are enqueued
+    hierarchies do that); =0 keeps them on the frame's stream; "tail"
+    (VKRHIP_OVERLAP_TAIL=2): scan and gather go there as well, the next frame starts
+    right behind the classify and rewrites the world matrices while the previous
+    frame's lists and draws are still being made. Frames are enqueued
     in pairs with different dirty sets and nothing read in between, so the second
     frame's transform overwrites world matrices while the first frame's rows may
     still be in flight; then a caller's kernel-side read is imitated with join() +
@@ -598,7 +601,8 @@ def test_transparent_sort_on_second_stream(oracle, monkeypatch, overlap, blend_f
     import torch
     from vulkan_renderer_amd.parallel import wrap_device
     synth = _synth()
-    monkeypatch.setenv("VKRHIP_OVERLAP_SORT", overlap)
+    monkeypatch.setenv("VKRHIP_OVERLAP_SORT", "2" if overlap == "tail" else overlap)
+    monkeypatch.setenv("VKRHIP_OVERLAP_TAIL", "2" if overlap == "tail" else "0")
     sc = synth.deep_scene(260000, depth=5, seed=21, fanout=9, roots=11, blend_fraction=blend_fraction)
     vs = synth.camera_views(cascades=2, far=900.0)
     planes, required = view_set(vs)

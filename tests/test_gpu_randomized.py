@@ -30,7 +30,7 @@ def _frame_reference(oracle, sc, state, planes, required, vs, partition_capacity
 # VKR_RANDOM_SEEDS widens the sweep for a soak run and VKR_RANDOM_SCALE multiplies the
 # scene sizes; seeds from 12 on also draw probe views (up to 64 views in all)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKR_RANDOM_SEEDS", "16"))))
-def test_random_scene_over_frames(oracle, seed, staged_mode):
+def test_random_scene_over_frames(oracle, seed, staged_mode, tail_mode):
     from helpers import compare_frame, hip_scene_for, view_set
     from vulkan_renderer_amd import synth
     rng = np.random.default_rng(1000 + seed)

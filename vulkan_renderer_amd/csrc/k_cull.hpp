@@ -164,6 +164,8 @@ struct CullArgs {
   const float4 *view;      // camera view matrix columns
   uint8_t *tvis;           // transparent_visible
   uint64_t *tkey;          // sort key of visible blend rows (sparse, per candidate)
+  float4 *tworld_sparse;   // optional: the world matrix of every visible blend row, under its
+                           // candidate index (see classify_candidate)
   float4 *world_bounds;    // optional (cx,cy,cz,r) per candidate
   unsigned long long *seg_masks;  // [segment][seg_record_words(views)] survivor masks (see CullShared)
   uint32_t *seg_counts;    // [row][seg_stride] survivors of the row in the segment
@@ -470,6 +472,18 @@ __device__ __forceinline__ uint32_t classify_candidate(const CullArgs &a, CullSh
     depth = depth > 0.0f ? depth : 0.0f;
     const uint32_t tie_breaker = (uint32_t)(a.index_base + i) + 1u;
     a.tkey[i] = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)tie_breaker;
+    // When the frame's compaction, sort and emission run beside the NEXT frame's
+    // transform, the emission can no longer read the row's matrix from world[]: it
+    // is set aside here, under the candidate's own index (a visible blend row is
+    // rare - well under one row in a hundred - so the copy is a few scattered
+    // stores, and no place in a compact array has to be known yet).
+    if (a.tworld_sparse != nullptr) {  // wave-uniform
+      float4 *aside = a.tworld_sparse + i * 4u;
+      aside[0] = m.c[0];
+      aside[1] = m.c[1];
+      aside[2] = m.c[2];
+      aside[3] = m.c[3];
+    }
   }
   {
     const unsigned long long mt = __ballot(tv);

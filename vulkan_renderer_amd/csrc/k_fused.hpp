@@ -312,6 +312,7 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
     own_sgprs(a.c.view);
     own_sgprs(a.c.tvis);
     own_sgprs(a.c.tkey);
+    own_sgprs(a.c.tworld_sparse);
     own_sgprs(a.c.world_bounds);
     own_sgprs(a.c.seg_masks);
     own_sgprs(a.c.seg_counts);

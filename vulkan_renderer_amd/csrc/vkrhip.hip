@@ -120,10 +120,20 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> row_totals;  // survivors per count row, written by k_scan
   // Segment tables of the compaction: a segment is the stretch of candidates one
   // classify block handled (at most 1024). Sized for the hierarchy in use.
-  DevBuf<unsigned long long> seg_masks;  // [seg_stride][seg_record_words(max_views)] survivor masks
-  DevBuf<uint32_t> seg_counts;   // [max_views * 4 + 1][seg_stride]
-  DevBuf<uint32_t> seg_offsets;  // same shape, exclusive prefix
-  DevBuf<uint32_t> seg_first;    // [seg_stride]
+  // What the classify blocks write and the compaction reads exists twice once a
+  // frame's compaction runs beside the next frame's classify (see frame_tail): a
+  // frame uses copy `par`.
+  DevBuf<unsigned long long> seg_masks2[2];  // [seg_stride][seg_record_words(max_views)] survivor masks
+  DevBuf<uint32_t> seg_counts2[2];  // [max_views * 4 + 1][seg_stride]
+  DevBuf<uint32_t> seg_offsets;     // same shape, exclusive prefix
+  DevBuf<uint32_t> seg_first2[2];   // [seg_stride]
+  uint32_t par = 0;           // copy of the frame being enqueued
+  bool second_copy = false;   // copy 1 of the tables above is allocated
+  bool want_second = false;   // ... or will be, the next time the tables are (re)allocated
+  uint64_t seg_alloc_stride = 0;  // columns the tables were allocated for (seg_stride: those in use)
+  DevBuf<unsigned long long> &seg_masks() { return seg_masks2[par]; }
+  DevBuf<uint32_t> &seg_counts() { return seg_counts2[par]; }
+  DevBuf<uint32_t> &seg_first() { return seg_first2[par]; }
   uint64_t seg_stride = 0;
   uint64_t segments = 0;  // segments of the frame being enqueued
   // Whether the classify blocks of the fused kernel expand their own survivors
@@ -131,13 +141,16 @@ struct vkrhip_ctx {
   // least kStagedMinSegments segments (default), 2 every frame the variants exist for.
   int staged_compaction = 1;
   bool frame_staged = false;      // the frame's classify blocks staged their survivors (k_place follows)
-  // Per-frame counters: two blocks of [sharded counters | tie counters]. Frames
-  // alternate between them; the scan kernel of a frame zeroes the other block,
-  // so steady-state frames start without a fill. block_clean falls back to a
-  // fill whenever a frame ran without that kernel.
+  // Per-frame counters: three blocks of [sharded counters | tie counters | sort
+  // state | caster box]. Frames take them in turn; the scan kernel of a frame
+  // zeroes the block of the frame after the next one (the previous frame's block,
+  // whose readers are done by then: they precede the scan on its stream, or the
+  // frame's stream has joined them), so steady-state frames start without a fill.
+  // block_clean falls back to a fill whenever a frame ran without that kernel.
+  static constexpr uint32_t kBlocks = 3;
   DevBuf<uint8_t> frame_zero;
   uint32_t cur_block = 0;
-  bool block_clean[2] = {true, true};
+  bool block_clean[kBlocks] = {true, true, true};
   static constexpr size_t kCountersBytes = sizeof(uint32_t) * CNT_COUNT * STAT_SHARDS;
   static constexpr size_t kTiesBytes = sizeof(unsigned long long) * VKRHIP_MAX_VIEWS * TIE_SHARDS;
   static constexpr size_t kSortStateBytes = sizeof(SortState);
@@ -156,7 +169,11 @@ struct vkrhip_ctx {
   unsigned long long *ties() const {
     return reinterpret_cast<unsigned long long *>(counter_block(cur_block) + kCountersBytes);
   }
-  DevBuf<uint64_t> tkey;
+  DevBuf<uint64_t> tkey2[2];  // copy `par`, like the segment tables
+  DevBuf<uint64_t> &tkey() { return tkey2[par]; }
+  // The world matrix of every visible blend row under its candidate index, written
+  // by the classify blocks of a frame whose whole tail runs on the second stream.
+  DevBuf<float4> tworld_sparse[2];
   DevBuf<uint32_t> visible;
   uint64_t visible_stride = 0;
   DevBuf<float4> world_bounds;
@@ -216,10 +233,24 @@ struct vkrhip_ctx {
   // Sort and emission of the transparent draws run on a stream of their own, beside
   // the next frame's transform and cull (they read nothing those overwrite).
   hipStream_t tstream = nullptr;
-  hipEvent_t ev_gathered = nullptr;  // main stream: the frame's keys and set-aside rows are complete
-  hipEvent_t ev_emitted = nullptr;   // side stream: the frame's draws are complete
-  bool side_pending = false;         // ev_emitted has not been waited for yet
+  hipEvent_t ev_gathered = nullptr;  // main stream: what the side stream's work of the frame reads is complete
+  // Side stream: everything a frame put there is done. One event per copy `par`, so
+  // that a wait that is still queued never sees its event recorded again.
+  hipEvent_t ev_side[2] = {nullptr, nullptr};
+  bool side_pending[2] = {false, false};  // ev_side[k] has not been waited for yet
+  int side_last = -1;                     // the event recorded last (the side stream runs in order)
+  uint32_t side_turn = 0;                 // the event the next batch of side-stream work records
+  // Side-stream work that must be over before the main stream touches something
+  // again, as the index of the event recorded behind it (-1: none): the batch that
+  // read copy k of the segment tables, and the batch whose scan zeroes counter block b.
+  int copy_event[2] = {-1, -1};
+  int block_event[3] = {-1, -1, -1};
   int overlap_sort = 1;             // VKRHIP_OVERLAP_SORT: 0 one stream, 1 large hierarchies, 2 always
+  // The whole tail of a frame (scan, gather, sort, emission) on the second stream:
+  // VKRHIP_OVERLAP_TAIL 0 never, 1 large hierarchies (default), 2 whenever the
+  // fused kernel runs.
+  int overlap_tail = 1;
+  bool frame_tail = false;  // the frame being enqueued does that
   DevBuf<uint32_t> tsrc;
   DevBuf<float4> tworld;
   hipEvent_t x_packed = nullptr;
@@ -406,9 +437,40 @@ struct StageTimer {
 // wait; the host does not block). Called wherever the main stream, or the host
 // through it, is about to read the draws or to change what the emission reads.
 int join_side(vkrhip_ctx *c) {
-  if (!c->side_pending) return VKRHIP_OK;
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_emitted, 0));
-  c->side_pending = false;
+  if (c->side_last < 0 || !c->side_pending[c->side_last]) return VKRHIP_OK;
+  // (the side stream runs in order: behind its last event nothing of it is left)
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[c->side_last], 0));
+  c->side_pending[0] = c->side_pending[1] = false;
+  return VKRHIP_OK;
+}
+
+// Orders the main stream behind one batch of side-stream work (see copy_event,
+// block_event): normally the batch of two frames ago, long finished. A later
+// record of the same event covers the earlier one.
+int wait_side_event(vkrhip_ctx *c, int e) {
+  if (e < 0 || !c->side_pending[e]) return VKRHIP_OK;
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[e], 0));
+  c->side_pending[e] = false;
+  if (c->side_last == e) c->side_pending[e ^ 1] = false;  // recorded earlier: covered as well
+  return VKRHIP_OK;
+}
+
+// Marks the end of a batch of side-stream work. Returns the event's index.
+int record_side(vkrhip_ctx *c, int *out_event) {
+  const int e = (int)c->side_turn;
+  HIP_TRY(c, hipEventRecord(c->ev_side[e], c->tstream));
+  c->side_pending[e] = true;
+  c->side_last = e;
+  c->side_turn ^= 1u;
+  if (out_event) *out_event = e;
+  return VKRHIP_OK;
+}
+
+// The host waits for the side stream (entry points that free or rewrite what its
+// kernels read).
+int drain_side(vkrhip_ctx *c) {
+  if (c->tstream) HIP_TRY(c, hipStreamSynchronize(c->tstream));
+  c->side_pending[0] = c->side_pending[1] = false;
   return VKRHIP_OK;
 }
 
@@ -638,6 +700,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   if (const char *env = std::getenv("VKRHIP_STREAMING")) c->streaming_mode = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_STAGED")) c->staged_compaction = std::atoi(env);
+  if (const char *env = std::getenv("VKRHIP_OVERLAP_TAIL")) c->overlap_tail = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
@@ -651,7 +714,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->tstream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
+    for (auto &e : c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
     TRY(dev_alloc(c, c->local, mn * 4));
     TRY(dev_alloc(c, c->world, mn * 4));
@@ -670,9 +733,9 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->camera_view, 4));
     TRY(dev_alloc(c, c->tvis, mc));
-    TRY(dev_alloc(c, c->frame_zero, 2u * vkrhip_ctx::kBlockBytes));
+    TRY(dev_alloc(c, c->frame_zero, vkrhip_ctx::kBlocks * vkrhip_ctx::kBlockBytes));
     HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, c->frame_zero.count, c->stream));
-    TRY(dev_alloc(c, c->tkey, mc));
+    TRY(dev_alloc(c, c->tkey2[0], mc));
     TRY(dev_alloc(c, c->states, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->row_totals, CULL_MAX_ROWS));
     HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
@@ -702,9 +765,12 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->tstream) (void)hipStreamDestroy(c->tstream);
   if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
-  if (c->ev_emitted) (void)hipEventDestroy(c->ev_emitted);
+  for (auto &e : c->ev_side) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
   c->tstream = nullptr;
-  c->ev_gathered = c->ev_emitted = nullptr;
+  c->ev_gathered = nullptr;
   dev_free(c->tsrc);
   dev_free(c->tworld);
   for (EventPair &ev : c->pending) {
@@ -735,7 +801,13 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->tie_eps);
   dev_free(c->required);
   dev_free(c->camera_view);
-  dev_free(c->seg_masks);
+  for (int k = 0; k < 2; ++k) {
+    dev_free(c->seg_masks2[k]);
+    dev_free(c->seg_counts2[k]);
+    dev_free(c->seg_first2[k]);
+    dev_free(c->tkey2[k]);
+    dev_free(c->tworld_sparse[k]);
+  }
   dev_free(c->pub_geometries);
   dev_free(c->pub_submeshes);
   dev_free(c->pub_materials);
@@ -748,12 +820,9 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->packed_instances);
   dev_free(c->visible_rows);
   dev_free(c->commands);
-  dev_free(c->seg_counts);
   dev_free(c->seg_offsets);
-  dev_free(c->seg_first);
   dev_free(c->tvis);
   dev_free(c->frame_zero);
-  dev_free(c->tkey);
   dev_free(c->states);
   dev_free(c->row_totals);
   dev_free(c->visible);
@@ -992,8 +1061,7 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
   TRY(bind_device(c));
   // the side stream may still emit the last frame's draws from the identity words
   // and the key buffers that are replaced below
-  if (c->tstream) HIP_TRY(c, hipStreamSynchronize(c->tstream));
-  c->side_pending = false;
+  TRY(drain_side(c));
   uint64_t blend = 0;
   std::vector<uint32_t> transmissive;
   for (uint64_t i = 0; i < n; ++i) {
@@ -1119,6 +1187,7 @@ int vkrhip_set_publication(vkrhip_ctx *c, const vkrhip_geometry_entry *geometrie
     if ((uint64_t)geometries[g].submesh_offset + geometries[g].submesh_count > submesh_count)
       return fail(c, VKRHIP_ERR_ARG, "geometry %u names submeshes beyond the submesh table", g + 1u);
   TRY(bind_device(c));
+  TRY(drain_side(c));  // a gather on the second stream may still read the row index map
   const uint64_t mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
   TRY(dev_alloc(c, c->pub_geometries, std::max<uint32_t>(geometry_capacity, 1)));
   TRY(dev_alloc(c, c->pub_submeshes, std::max<uint32_t>(submesh_count, 1)));
@@ -1248,11 +1317,12 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.required = c->required.p;
   a.view = c->camera_view.p;
   a.tvis = c->tvis.p;
-  a.tkey = c->tkey.p;
+  a.tkey = c->tkey().p;
+  a.tworld_sparse = c->frame_tail ? c->tworld_sparse[c->par].p : nullptr;
   a.world_bounds = c->world_bounds.p;
-  a.seg_masks = c->seg_masks.p;
-  a.seg_counts = c->seg_counts.p;
-  a.seg_first = c->seg_first.p;
+  a.seg_masks = c->seg_masks().p;
+  a.seg_counts = c->seg_counts().p;
+  a.seg_first = c->seg_first().p;
   a.counters = c->counters();
   a.ties = c->ties();
   a.caster_bounds = (c->frame_stages & VKRHIP_STAGE_CASTER_BOUNDS) ? c->caster_box() : nullptr;
@@ -1332,32 +1402,58 @@ static int launch_transform(vkrhip_ctx *c) {
   return VKRHIP_OK;
 }
 
-// Grows the segment tables to hold `segments` columns (whole uint4s per row).
+// Grows the segment tables to hold `segments` columns (whole uint4s per row), and
+// gives them their second copy once a frame wants one.
 static int ensure_segments(vkrhip_ctx *c, uint64_t segments) {
   const uint64_t need = (segments + 3u) & ~(uint64_t)3u;
-  if (need <= c->seg_stride) return VKRHIP_OK;
+  const bool add_copy = c->want_second && !c->second_copy;
+  if (need <= c->seg_stride && !add_copy) return VKRHIP_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  dev_free(c->seg_counts);
-  dev_free(c->seg_offsets);
-  dev_free(c->seg_first);
-  dev_free(c->seg_masks);
-  c->seg_stride = 0;
-  const uint64_t stride = need + need / 4u;  // head room for a growing scene
+  TRY(drain_side(c));
+  uint64_t stride = c->seg_alloc_stride;
+  if (need > c->seg_stride) {
+    for (int k = 0; k < 2; ++k) {
+      dev_free(c->seg_counts2[k]);
+      dev_free(c->seg_first2[k]);
+      dev_free(c->seg_masks2[k]);
+    }
+    dev_free(c->seg_offsets);
+    c->seg_stride = 0;
+    c->second_copy = false;
+    stride = need + need / 4u;  // head room for a growing scene
+  }
   const size_t rows = (size_t)c->cfg.max_views * 4u + 1u;
-  TRY(dev_alloc(c, c->seg_counts, rows * stride));
-  TRY(dev_alloc(c, c->seg_offsets, rows * stride));
-  TRY(dev_alloc(c, c->seg_first, stride));
+  const uint64_t kept = stride & ~(uint64_t)3u;
   // (large enough for either use: the segments' records, or the blend-row masks and
   // the staging lists of segment_finish_staged)
-  const uint64_t kept = stride & ~(uint64_t)3u;
-  TRY(dev_alloc(c, c->seg_masks,
-                std::max<size_t>(stride * seg_record_words(c->cfg.max_views),
-                                 c->staged_compaction
-                                     ? staged_table_words(kept, std::min<uint32_t>(c->cfg.max_views, STAGED_MAX_VIEWS))
-                                     : 0u)));
-  HIP_TRY(c, hipMemsetAsync(c->seg_masks.p, 0, c->seg_masks.count * sizeof(unsigned long long), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->seg_first.p, 0, c->seg_first.count * sizeof(uint32_t), c->stream));
-  c->seg_stride = stride & ~(uint64_t)3u;
+  const size_t mask_words = std::max<size_t>(
+      stride * seg_record_words(c->cfg.max_views),
+      c->staged_compaction ? staged_table_words(kept, std::min<uint32_t>(c->cfg.max_views, STAGED_MAX_VIEWS)) : 0u);
+  const int copies = c->want_second ? 2 : 1;
+  for (int k = 0; k < copies; ++k) {
+    if (c->seg_masks2[k].p) continue;  // copy 0 when only the second copy is added
+    TRY(dev_alloc(c, c->seg_counts2[k], rows * stride));
+    TRY(dev_alloc(c, c->seg_first2[k], stride));
+    TRY(dev_alloc(c, c->seg_masks2[k], mask_words));
+    HIP_TRY(c, hipMemsetAsync(c->seg_masks2[k].p, 0, c->seg_masks2[k].count * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->seg_first2[k].p, 0, c->seg_first2[k].count * sizeof(uint32_t), c->stream));
+  }
+  TRY(dev_alloc(c, c->seg_offsets, rows * stride));
+  c->seg_alloc_stride = stride;
+  c->seg_stride = kept;
+  c->second_copy = copies == 2;
+  if (!c->second_copy) c->par = 0;
+  return VKRHIP_OK;
+}
+
+// What a frame needs whose whole tail runs on the second stream: the sparse keys
+// and the set-aside matrices twice (the segment tables get their second copy in
+// ensure_segments).
+static int ensure_tail_buffers(vkrhip_ctx *c) {
+  const uint64_t mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
+  TRY(dev_alloc(c, c->tkey2[1], mc));
+  for (auto &b : c->tworld_sparse) TRY(dev_alloc(c, b, mc * 4u));
+  c->want_second = true;
   return VKRHIP_OK;
 }
 
@@ -1537,16 +1633,18 @@ static int launch_classify(vkrhip_ctx *c, bool bounds_out) {
   return VKRHIP_OK;
 }
 
-static int launch_compaction(vkrhip_ctx *c, bool set_aside) {
+// `on`: the frame's stream, or the second stream when the whole tail runs there.
+static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
   const uint64_t segments = c->n_cand ? c->segments : 0;
   if (!segments) {  // nothing to compact: empty states, zero transparent rows (counters are zeroed)
-    HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->states.p, 0, sizeof(CompactionState) * VKRHIP_MAX_VIEWS, on));
     return VKRHIP_OK;
   }
+  const uint32_t next_block = (c->cur_block + 2u) % vkrhip_ctx::kBlocks;
   {
-    StageTimer timer(c, VKRHIP_TIMER_SCAN);
+    StageTimer timer(c, VKRHIP_TIMER_SCAN, on);
     ScanArgs s{};
-    s.seg_counts = c->seg_counts.p;
+    s.seg_counts = c->seg_counts().p;
     s.seg_offsets = c->seg_offsets.p;
     s.row_totals = c->row_totals.p;
     s.counters = c->counters();
@@ -1555,21 +1653,21 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside) {
     s.views = c->views;
     s.transparent_capacity = c->tcap;
     s.host_hint = c->host_hint;
-    s.clear = reinterpret_cast<uint32_t *>(c->counter_block(c->cur_block ^ 1u));
+    s.clear = reinterpret_cast<uint32_t *>(c->counter_block(next_block));
     s.clear_words = (uint32_t)(vkrhip_ctx::kBlockBytes / sizeof(uint32_t));
-    hipLaunchKernelGGL(k_scan, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, c->stream, s);
+    hipLaunchKernelGGL(k_scan, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, on, s);
     HIP_TRY(c, hipGetLastError());
-    c->block_clean[c->cur_block ^ 1u] = true;
+    c->block_clean[next_block] = true;
   }
   {
-    StageTimer timer(c, VKRHIP_TIMER_SCATTER);
+    StageTimer timer(c, VKRHIP_TIMER_SCATTER, on);
     GatherArgs g{};
-    g.seg_masks = c->seg_masks.p;
-    g.seg_counts = c->seg_counts.p;
+    g.seg_masks = c->seg_masks().p;
+    g.seg_counts = c->seg_counts().p;
     g.seg_offsets = c->seg_offsets.p;
-    g.seg_first = c->seg_first.p;
+    g.seg_first = c->seg_first().p;
     g.row_totals = c->row_totals.p;
-    g.tkey = c->tkey.p;
+    g.tkey = c->tkey().p;
     g.remap = c->published ? c->packed_index.p : nullptr;
     g.states = c->states.p;
     g.visible = c->visible.p;
@@ -1588,7 +1686,7 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside) {
     g.partition_capacity = c->cfg.partition_capacity;
     // (a wave of k_gather takes one segment, a wave of k_place PLACE_SEGS)
     const unsigned grid = (unsigned)ceil_div(segments, (GATHER_BLOCK / 64) * (c->frame_staged ? PLACE_SEGS : 1u));
-    hipLaunchKernelGGL(c->frame_staged ? k_place : k_gather, dim3(grid), dim3(GATHER_BLOCK), 0, c->stream, g);
+    hipLaunchKernelGGL(c->frame_staged ? k_place : k_gather, dim3(grid), dim3(GATHER_BLOCK), 0, on, g);
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
@@ -1605,19 +1703,46 @@ constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
 // does a caller's own stream (vkrhip_set_stream promises all work on it) and a
 // context with the multi-GPU exchange configured (its pack needs the sorted keys
 // right behind the frame, which leaves nothing to overlap with).
+static bool second_stream_usable(const vkrhip_ctx *c) {
+  return c->x_world == 0 && c->stream == c->own_stream;
+}
 static bool sort_on_second_stream(const vkrhip_ctx *c) {
-  return c->x_world == 0 && c->stream == c->own_stream &&
+  return second_stream_usable(c) &&
          (c->overlap_sort >= 2 || (c->overlap_sort == 1 && c->n_nodes >= OVERLAP_MIN_NODES));
+}
+
+// Whether the WHOLE tail of the frame - scan, gather, sort, emission - goes to the
+// second stream, beside the next frame's transform and classify. The next frame
+// then starts right behind this frame's last classify launch. Nothing the tail
+// reads may be rewritten by that frame: the segment tables and sparse keys exist
+// twice, and the classify blocks set the visible blend rows' world matrices aside
+// themselves (CullArgs::tworld_sparse), so the fused kernel is a precondition.
+// Work of another stream only gets blocks placed while the running grid has none
+// left to place, i.e. while a launch drains: a hierarchy's frame opens with small
+// launches (merged top levels, the first large level) beside which the tail runs,
+// a flat scene's single launch offers no such window and keeps the tail where it
+// is. Stages that consume the frame's lists or counters right behind it
+// (candidate rows' published totals, pack, encode) keep it there as well.
+static bool tail_on_second_stream(const vkrhip_ctx *c, uint32_t stages, bool fused) {
+  if (!fused || !second_stream_usable(c) || !(stages & VKRHIP_STAGE_TRANSPARENT)) return false;
+  if (stages & (VKRHIP_STAGE_CANDIDATES | VKRHIP_STAGE_PACK | VKRHIP_STAGE_ENCODE)) return false;
+  if (c->overlap_tail >= 2) return true;
+  const bool hierarchy = c->level_offsets.size() > 2 && c->parent.p;
+  return c->overlap_tail == 1 && c->overlap_sort != 0 && hierarchy && c->n_nodes >= OVERLAP_MIN_NODES;
 }
 
 static EmitArgs emit_args(vkrhip_ctx *c, bool set_aside) {
   EmitArgs e{};
   e.keys = c->keys_a.p;
   e.counters = c->counters();
-  e.tworld = set_aside ? c->tworld.p : nullptr;
+  e.tworld = set_aside && !c->frame_tail ? c->tworld.p : nullptr;
   e.tsrc = c->tsrc.p;
   e.world = c->world.p;
   e.node = c->node_identity ? nullptr : c->node.p;
+  if (c->frame_tail) {  // the classify blocks set the matrices aside, under the candidate index
+    e.world = c->tworld_sparse[c->par].p;
+    e.node = nullptr;
+  }
   e.ident = c->ident.p;
   e.draws = c->draws.p;
   e.instances = c->instances.p;
@@ -1644,8 +1769,10 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
   hipStream_t on = c->stream;
   if (overlap) {
     on = c->tstream;
-    HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(on, c->ev_gathered, 0));
+    if (!c->frame_tail) {  // (the whole tail: the side stream already waits behind the classify)
+      HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(on, c->ev_gathered, 0));
+    }
   }
   if (expected <= RANK_LIMIT) {
     StageTimer timer(c, VKRHIP_TIMER_SORT, on);
@@ -1691,8 +1818,12 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
     }
   }
   if (overlap) {
-    HIP_TRY(c, hipEventRecord(c->ev_emitted, on));
-    c->side_pending = true;
+    int e = -1;
+    TRY(record_side(c, &e));
+    if (c->frame_tail) {
+      c->copy_event[c->par] = e;  // the batch read this copy of the segment tables ...
+      c->block_event[(c->cur_block + 2u) % vkrhip_ctx::kBlocks] = e;  // ... and its scan zeroes this block
+    }
   }
   return VKRHIP_OK;
 }
@@ -1761,9 +1892,12 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     StageTimer frame_timer(c, VKRHIP_TIMER_FRAME);
     // this frame's counter block is normally already zero (cleared by the
     // previous frame's scan kernel)
-    c->cur_block ^= 1u;
+    c->cur_block = (c->cur_block + 1u) % vkrhip_ctx::kBlocks;
+    // a scan on the second stream may be the one that zeroes this block (two frames ago)
+    TRY(wait_side_event(c, c->block_event[c->cur_block]));
+    c->block_event[c->cur_block] = -1;
     if (!c->block_clean[c->cur_block]) {
-      // the block was last used two frames ago, and that frame's sort and emission
+      // the block was last used three frames ago, and that frame's sort and emission
       // (side stream) read its count, histograms and tickets: they must be done
       // before it is zeroed (a frame that culls joins anyway, behind its classify)
       TRY(join_side(c));
@@ -1774,19 +1908,37 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     // (the occlusion test lives in the stand-alone classify kernel only)
     const bool fused = cull && c->hzb_mips == 0 && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
                        c->n_cand > 0 && c->n_cand <= c->n_nodes && c->level_offsets.size() > 1;
+    c->frame_tail = tail_on_second_stream(c, stages, fused);
+    if (c->frame_tail) TRY(ensure_tail_buffers(c));
+    if (cull) {
+      // frames alternate between the copies of the segment tables; the batch of
+      // side-stream work that read this frame's copy must be over before the
+      // classify blocks rewrite it
+      if (c->second_copy) c->par ^= 1u;
+      TRY(wait_side_event(c, c->copy_event[c->par]));
+      c->copy_event[c->par] = -1;
+    }
     if (fused) {
       TRY(launch_fused(c, bounds_out));
     } else {
       if (stages & VKRHIP_STAGE_TRANSFORM) TRY(launch_transform(c));
       if (cull) TRY(launch_classify(c, bounds_out));
     }
-    // the previous frame's sort and emission (side stream) still own the other
-    // counter block, the key buffers and the set-aside rows: the scan zeroes that
-    // block and the gather refills the buffers
-    if (cull) TRY(join_side(c));
-    const bool overlap = (stages & VKRHIP_STAGE_TRANSPARENT) && sort_on_second_stream(c);
-    if (cull) TRY(launch_compaction(c, overlap));
-    if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c, overlap));
+    if (c->frame_tail) {
+      // the tail waits for the classify on the second stream; the frame's stream goes on
+      HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->tstream, c->ev_gathered, 0));
+      TRY(launch_compaction(c, false, c->tstream));
+      TRY(launch_transparent(c, true));
+    } else {
+      // the previous frame's work on the side stream still owns the previous counter
+      // block, the key buffers, the lists and the set-aside rows: the scan zeroes
+      // that block and the gather refills the buffers
+      if (cull) TRY(join_side(c));
+      const bool overlap = (stages & VKRHIP_STAGE_TRANSPARENT) && sort_on_second_stream(c);
+      if (cull) TRY(launch_compaction(c, overlap, c->stream));
+      if (stages & VKRHIP_STAGE_TRANSPARENT) TRY(launch_transparent(c, overlap));
+    }
     if (stages & VKRHIP_STAGE_CANDIDATES) {
       TRY(launch_candidates(c));
       // the frame's totals, for vkrhip_fill_world_payload: summed on the device and
