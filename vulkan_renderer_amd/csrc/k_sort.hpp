@@ -299,7 +299,14 @@ __device__ __forceinline__ unsigned long long sort_status(uint32_t serial, uint3
 // promised to start in index order). The keys a block requests before it knows
 // its tile are those of tile blockIdx.x, which is the tile it gets when the
 // blocks start in order; otherwise it requests its tile's keys again.
-__global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
+//
+// At most 128 registers (four waves per SIMD): beside the next frame's large level
+// launch - four waves of 128 registers per SIMD, the whole register file - a block
+// of this kernel is placed as soon as one block of that grid retires. With 204
+// registers it needed two of them to retire on the same SIMD at once, which does
+// not happen before the grid has no block left to place: a pass then sat through
+// the whole launch (400 us for 12 us of work).
+__global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sort_pass(SortArgs a) {
   __shared__ uint32_t s_whist[4][SORT_RADIX];  // per-wave digit counts, then bases
   __shared__ uint32_t s_wave[SORT_BLOCK / 64];
   __shared__ uint32_t s_tile;
@@ -354,9 +361,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(SortArgs a) {
     // look back: keys of this digit in the tiles before this one
     uint32_t before = 0u;
     if (tile != 0u) {
-      // thirty-two tiles per step, nearest first: their status words are independent
-      // loads, so a step costs one memory round trip, not thirty-two
-      constexpr uint32_t LOOK = 32;
+      // twelve tiles per step, nearest first: their status words are independent
+      // loads, so a step costs one memory round trip, not twelve (thirty-two per
+      // step measured no faster and cost 80 registers more)
+      constexpr uint32_t LOOK = 12;
       uint32_t polls = 0u;
       bool done = false;
       for (uint32_t hi = tile; hi != 0u && !done;) {

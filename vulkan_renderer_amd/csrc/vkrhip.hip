@@ -233,6 +233,7 @@ struct vkrhip_ctx {
   // Sort and emission of the transparent draws run on a stream of their own, beside
   // the next frame's transform and cull (they read nothing those overwrite).
   hipStream_t tstream = nullptr;
+  hipEvent_t attach_stop = nullptr;  // recorded by the next heavy launch itself, as its completion signal
   hipEvent_t ev_gathered = nullptr;  // main stream: what the side stream's work of the frame reads is complete
   // Side stream: everything a frame put there is done. One event per copy `par`, so
   // that a wait that is still queued never sees its event recorded again.
@@ -437,10 +438,11 @@ struct StageTimer {
 // wait; the host does not block). Called wherever the main stream, or the host
 // through it, is about to read the draws or to change what the emission reads.
 int join_side(vkrhip_ctx *c) {
-  if (c->side_last < 0 || !c->side_pending[c->side_last]) return VKRHIP_OK;
   // (the side stream runs in order: behind its last event nothing of it is left)
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[c->side_last], 0));
-  c->side_pending[0] = c->side_pending[1] = false;
+  if (c->side_last >= 0 && c->side_pending[c->side_last]) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[c->side_last], 0));
+    c->side_pending[0] = c->side_pending[1] = false;
+  }
   return VKRHIP_OK;
 }
 
@@ -448,10 +450,12 @@ int join_side(vkrhip_ctx *c) {
 // block_event): normally the batch of two frames ago, long finished. A later
 // record of the same event covers the earlier one.
 int wait_side_event(vkrhip_ctx *c, int e) {
-  if (e < 0 || !c->side_pending[e]) return VKRHIP_OK;
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[e], 0));
-  c->side_pending[e] = false;
-  if (c->side_last == e) c->side_pending[e ^ 1] = false;  // recorded earlier: covered as well
+  if (e < 0) return VKRHIP_OK;
+  if (c->side_pending[e]) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[e], 0));
+    c->side_pending[e] = false;
+    if (c->side_last == e) c->side_pending[e ^ 1] = false;  // recorded earlier: covered as well
+  }
   return VKRHIP_OK;
 }
 
@@ -513,8 +517,15 @@ void launch_timed(vkrhip_ctx *c, int timer, bool first_of_stage, K kernel, dim3 
       ev.samples = first_of_stage ? 1 : 0;
       hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, c->stream, ev.start, ev.stop, 0u, args);
       c->pending.push_back(ev);
+      if (c->attach_stop) (void)hipEventRecord(c->attach_stop, c->stream);
+      c->attach_stop = nullptr;
       return;
     }
+  }
+  if (c->attach_stop) {  // the launch's own completion signal is the event: no packet of its own
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, c->stream, nullptr, c->attach_stop, 0u, args);
+    c->attach_stop = nullptr;
+    return;
   }
   hipLaunchKernelGGL(kernel, grid, block, lds, c->stream, args);
 }
@@ -1532,11 +1543,18 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
   TRY(ensure_segments(c, segments));
   bool first = true;
   uint64_t seg_base = 0;
+  // the frame's last launch (its completion releases the tail on the second stream)
+  int last_level = -1;
+  for (uint32_t l = l0; l < levels; ++l) {
+    uint32_t rounds = 4;
+    if (fused_level_grid(c, l, &rounds)) last_level = (int)l;
+  }
   if (l0) {
     FusedArgs a{};
     a.c = cull_args(c);
     top_args(c, a, cull_shared_bytes(c->views));
     a.seg_base = 0;
+    if (c->frame_tail && last_level < 0) c->attach_stop = c->ev_gathered;
     launch_fused_variant<true, true>(c, a, c->top_blocks, ties, bounds_out, first);
     first = false;
     seg_base = c->top_blocks;
@@ -1549,6 +1567,7 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.c = cull_args(c);
     a.seg_base = (uint32_t)seg_base;
     const bool root = l == 0 || !c->parent.p;
+    if (c->frame_tail && (int)l == last_level) c->attach_stop = c->ev_gathered;
     if (frame_streams(c)) {
       if (root)
         launch_fused_variant<false, false, true>(c, a, (unsigned)grid, ties, bounds_out, first);
@@ -1566,6 +1585,7 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
   c->segments = segments;
   c->force_flags = 0;
   if (!first) c->flags_cur ^= 1u;  // the launches wrote every node's flags to the other copy
+  if (c->frame_tail && first) HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));  // (no launch at all)
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
@@ -1717,18 +1737,26 @@ static bool sort_on_second_stream(const vkrhip_ctx *c) {
 // reads may be rewritten by that frame: the segment tables and sparse keys exist
 // twice, and the classify blocks set the visible blend rows' world matrices aside
 // themselves (CullArgs::tworld_sparse), so the fused kernel is a precondition.
-// Work of another stream only gets blocks placed while the running grid has none
-// left to place, i.e. while a launch drains: a hierarchy's frame opens with small
-// launches (merged top levels, the first large level) beside which the tail runs,
-// a flat scene's single launch offers no such window and keeps the tail where it
-// is. Stages that consume the frame's lists or counters right behind it
-// (candidate rows' published totals, pack, encode) keep it there as well.
+// A block of another stream is placed beside a running grid wherever its waves fit
+// next to that grid's: the large-level variant of the fused kernel holds four waves
+// of 128 registers per SIMD, i.e. the whole register file, and every block it
+// retires frees room for one wave of at most 128 registers per SIMD - which is why
+// every kernel of the tail is kept at or below that (a radix pass of 204 registers
+// waited for the grid's last blocks: 572 us per frame of the 16M-node hierarchy
+// against 564 us). Measured per frame, tail here / on the frame's stream: 16M-node
+// hierarchy with five views 564 / 597 us, 32M flat nodes with one view 921 / 936
+// us; with 64 views the fused kernel is bound by its vector instructions and the
+// gather's compete with them (1336 / 1304 us), and a frame of 1M nodes is too short
+// for the two cross-stream waits (43.8 / 42.6 us): many views and small scenes keep
+// the tail where it is. Stages that consume the frame's lists or counters right
+// behind it (candidate rows' published totals, pack, encode) keep it there as well.
+constexpr uint32_t TAIL_MAX_VIEWS = 8;
 static bool tail_on_second_stream(const vkrhip_ctx *c, uint32_t stages, bool fused) {
   if (!fused || !second_stream_usable(c) || !(stages & VKRHIP_STAGE_TRANSPARENT)) return false;
   if (stages & (VKRHIP_STAGE_CANDIDATES | VKRHIP_STAGE_PACK | VKRHIP_STAGE_ENCODE)) return false;
   if (c->overlap_tail >= 2) return true;
-  const bool hierarchy = c->level_offsets.size() > 2 && c->parent.p;
-  return c->overlap_tail == 1 && c->overlap_sort != 0 && hierarchy && c->n_nodes >= OVERLAP_MIN_NODES;
+  return c->overlap_tail == 1 && c->overlap_sort != 0 && c->n_nodes >= OVERLAP_MIN_NODES &&
+         c->views <= TAIL_MAX_VIEWS;
 }
 
 static EmitArgs emit_args(vkrhip_ctx *c, bool set_aside) {
@@ -1925,8 +1953,8 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
       if (cull) TRY(launch_classify(c, bounds_out));
     }
     if (c->frame_tail) {
-      // the tail waits for the classify on the second stream; the frame's stream goes on
-      HIP_TRY(c, hipEventRecord(c->ev_gathered, c->stream));
+      // the tail waits for the classify on the second stream (ev_gathered is the last
+      // classify launch's own completion signal); the frame's stream goes on
       HIP_TRY(c, hipStreamWaitEvent(c->tstream, c->ev_gathered, 0));
       TRY(launch_compaction(c, false, c->tstream));
       TRY(launch_transparent(c, true));
