@@ -471,6 +471,13 @@ int vkrhip_exchange_configure(vkrhip_ctx *ctx, uint32_t world, uint32_t vis_cap,
 int vkrhip_exchange_run(vkrhip_ctx *ctx);
 int vkrhip_exchange_finish(vkrhip_ctx *ctx, uint64_t *result_out,
                            const uint32_t **merged_visible_dev, const uint64_t **merged_keys_dev);
+/* Diagnosis of a stalled context (no reference counterpart), callable from another
+ * host thread while the owner is blocked in a wait: 1 = busy / not reached, 0 =
+ * idle / reached, -1 = does not exist, for out[0..2] the context's stream, its
+ * second stream and the exchange stream, out[3] the event behind the last classify
+ * launch, out[4..5] the events behind the second stream's batches, out[6..9] the
+ * packed / merged events of the two exchange buffer sets. Waits for nothing. */
+int vkrhip_debug_streams(vkrhip_ctx *ctx, int32_t *out, uint32_t n);
 
 /* ---- sharding a hierarchy over GPUs (no reference counterpart: the reference
  * runs on one GPU) -----------------------------------------------------------

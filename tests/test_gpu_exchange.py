@@ -330,12 +330,38 @@ def test_two_processes_one_gpu_over_gloo(oracle, tmp_path):
         assert (r0["vis"][off: off + count] == whole["visible"][v, :count]).all()
 
 
+@pytest.mark.parametrize("tail", ["0", "2"])
+def test_exchange_in_a_process_full_of_streams(tail):
+    """The process shape that stalled a context while its exchange stream had the
+    highest priority: eight more streams of default priority and two of high
+    priority alive in the process (what PyTorch's stream pools leave behind), the
+    frame's sort - or its whole tail - on the second stream, thirteen frames with
+    an exchange each. A fresh process that ends by its own watchdog (exit code 3)
+    if it stalls; tools/exchange_hang_probe.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VKRHIP_OVERLAP_SORT="2", VKRHIP_OVERLAP_TAIL=tail, PROBE_STREAMS="8",
+               PROBE_PRIORITY_STREAMS="2")
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "exchange_hang_probe.py"), "20"],
+                         env=env, capture_output=True, text=True, timeout=90)
+    assert run.returncode == 0 and "COMPLETED 13 frames" in run.stdout, run.stdout + run.stderr
+
+
+@pytest.mark.parametrize("streams", ["default", "sort", "tail"])
 @pytest.mark.parametrize("with_comm", [False, True])
-def test_native_exchange_single_rank(oracle, with_comm):
+def test_native_exchange_single_rank(oracle, with_comm, streams, monkeypatch):
     """The exchange inside the library (pack, RCCL all-gather or device copy,
-    merge on the second stream, two buffer sets): five frames in flight without a
-    host wait, growth from too-small blocks, result equal to the oracle."""
+    merge on the exchange stream, two buffer sets): five frames in flight without a
+    host wait, growth from too-small blocks, result equal to the oracle. "sort":
+    the frame's sort and emission on the second stream (VKRHIP_OVERLAP_SORT=2),
+    "tail": scan and gather as well (VKRHIP_OVERLAP_TAIL=2) - the pack then follows
+    them there and three streams are in play, which large scenes do by default."""
     import torch
+    if streams != "default":
+        monkeypatch.setenv("VKRHIP_OVERLAP_SORT", "2")
+        monkeypatch.setenv("VKRHIP_OVERLAP_TAIL", "2" if streams == "tail" else "0")
     from helpers import oracle_frame, view_set
     from vulkan_renderer_amd import HipScene, synth
     from vulkan_renderer_amd.parallel import RcclExchange

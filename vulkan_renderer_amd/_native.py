@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_exchange_block_words", "vkrhip_exchange_result_words", "vkrhip_exchange_pack",
     "vkrhip_exchange_merge", "vkrhip_comm_unique_id", "vkrhip_comm_init", "vkrhip_exchange_configure",
-    "vkrhip_exchange_run", "vkrhip_exchange_finish", "vkrhip_candidate_epoch", "vkrhip_set_hzb", "vkrhip_build_hzb", "vkrhip_read_hzb", "vkrhip_read_transmission_candidates",
+    "vkrhip_exchange_run", "vkrhip_exchange_finish", "vkrhip_debug_streams", "vkrhip_candidate_epoch", "vkrhip_set_hzb", "vkrhip_build_hzb", "vkrhip_read_hzb", "vkrhip_read_transmission_candidates",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize", "vkrhip_effective_visibility",
     "vkrhip_static_init", "vkrhip_exchange_merge_static",

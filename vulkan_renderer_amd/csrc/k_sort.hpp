@@ -226,8 +226,10 @@ constexpr uint32_t SORT_SPIN_LIMIT = 1u << 24;  // look-back polls before a bloc
 struct SortState {  // zero at the start of a frame
   uint32_t hist[SORT_PASSES][SORT_RADIX];  // keys per digit, per pass
   uint32_t ticket[SORT_PASSES];            // next tile of the pass
-  uint32_t stalled;                        // a look-back gave up (never expected)
-  uint32_t reserved[3];
+  uint32_t stalled;                        // a look-back gave up (never expected): 1 | pass << 8 | digit << 16
+  uint32_t stalled_tile;                   // ... the tile that gave up,
+  uint32_t stalled_on;                     // ... and the tile whose status it was waiting for
+  uint32_t reserved;
 };
 static_assert(sizeof(SortState) == SORT_STATE_WORDS * sizeof(uint32_t), "SortState layout");
 
@@ -401,8 +403,10 @@ __global__ __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
           if (++polls > SORT_SPIN_LIMIT) break;
           __builtin_amdgcn_s_sleep(1);
         }
-        if (polls > SORT_SPIN_LIMIT) {  // never expected: leave a mark and get out
-          a.state->stalled = 1u;
+        if (polls > SORT_SPIN_LIMIT) {  // never expected: leave a mark that names the place and get out
+          a.state->stalled = 1u | (a.pass << 8) | (t << 16);
+          a.state->stalled_tile = tile;
+          a.state->stalled_on = hi - 1u;
           break;
         }
         hi -= n;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -252,13 +253,15 @@ struct vkrhip_ctx {
   // fused kernel runs.
   int overlap_tail = 1;
   bool frame_tail = false;  // the frame being enqueued does that
+  int xdebug = 0;           // VKRHIP_XDEBUG: 16 logs the exchange's stream order, 32 makes
+                            // vkrhip_exchange_finish poll and name what is pending when it stalls
   DevBuf<uint32_t> tsrc;
   DevBuf<float4> tworld;
-  hipEvent_t x_packed = nullptr;
   struct ExchangeSet {
     DevBuf<uint32_t> send, recv, merged_visible;
     DevBuf<uint64_t> merged_keys, result;
-    hipEvent_t done = nullptr;
+    hipEvent_t packed = nullptr;  // the set's block is packed (the pack launch's own completion signal)
+    hipEvent_t done = nullptr;    // the set's merged outputs are complete
     bool in_flight = false;
   } xset[2];
   uint32_t x_world = 0, x_views = 0, x_vis_cap = 0, x_key_cap = 0, x_turn = 0;
@@ -380,11 +383,10 @@ void release_exchange(vkrhip_ctx *c) {
     dev_free(x.merged_keys);
     dev_free(x.result);
     if (x.done) (void)hipEventDestroy(x.done);
-    x.done = nullptr;
+    if (x.packed) (void)hipEventDestroy(x.packed);
+    x.done = x.packed = nullptr;
     x.in_flight = false;
   }
-  if (c->x_packed) (void)hipEventDestroy(c->x_packed);
-  c->x_packed = nullptr;
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
   c->xstream = nullptr;
 }
@@ -712,6 +714,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_STAGED")) c->staged_compaction = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_OVERLAP_TAIL")) c->overlap_tail = std::atoi(env);
+  if (const char *env = std::getenv("VKRHIP_XDEBUG")) c->xdebug = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
   auto run = [&]() -> int {
@@ -1720,12 +1723,10 @@ constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
 // overwrites: the gather sets the rows' world matrices aside, everything else
 // they read the gather wrote for them anyway. The two cross-stream waits cost
 // about a quarter of a small frame, so small hierarchies stay on one stream; so
-// does a caller's own stream (vkrhip_set_stream promises all work on it) and a
-// context with the multi-GPU exchange configured (its pack needs the sorted keys
-// right behind the frame, which leaves nothing to overlap with).
-static bool second_stream_usable(const vkrhip_ctx *c) {
-  return c->x_world == 0 && c->stream == c->own_stream;
-}
+// does a caller's own stream (vkrhip_set_stream promises all work on it). With the
+// multi-GPU exchange configured the pack follows the sort on the second stream
+// (vkrhip_exchange_run), so the context's stream does not wait for it either.
+static bool second_stream_usable(const vkrhip_ctx *c) { return c->stream == c->own_stream; }
 static bool sort_on_second_stream(const vkrhip_ctx *c) {
   return second_stream_usable(c) &&
          (c->overlap_sort >= 2 || (c->overlap_sort == 1 && c->n_nodes >= OVERLAP_MIN_NODES));
@@ -2000,15 +2001,18 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
   if (c->cfg.tie_epsilon > 0.f)
     HIP_TRY(c, hipMemcpyAsync(tie_shards.data(), c->ties(), tie_shards.size() * 8,
                               hipMemcpyDeviceToHost, c->stream));
-  uint32_t sort_stalled = 0;
+  uint32_t sort_stalled[3] = {0, 0, 0};
   // (the block the last radix sort ran in: a later frame without a sort has moved on)
-  HIP_TRY(c, hipMemcpyAsync(&sort_stalled,
+  HIP_TRY(c, hipMemcpyAsync(sort_stalled,
                             c->counter_block(c->sort_block) + vkrhip_ctx::kCountersBytes +
                                 vkrhip_ctx::kTiesBytes + offsetof(SortState, stalled),
-                            4, hipMemcpyDeviceToHost, c->stream));
+                            sizeof(sort_stalled), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (sort_stalled)
-    return fail(c, VKRHIP_ERR_STATE, "the draw-key sort gave up waiting for another tile's prefix");
+  if (sort_stalled[0])
+    return fail(c, VKRHIP_ERR_STATE,
+                "the draw-key sort gave up waiting for another tile's prefix (pass %u, digit %u: tile %u "
+                "waited for tile %u)",
+                (sort_stalled[0] >> 8) & 0xffu, sort_stalled[0] >> 16, sort_stalled[1], sort_stalled[2]);
   uint32_t cnt[CNT_COUNT] = {};
   for (uint32_t sh = 0; sh < STAT_SHARDS; ++sh)
     for (int k = 0; k < CNT_COUNT; ++k) cnt[k] += shards[sh * CNT_COUNT + k];
@@ -2556,8 +2560,11 @@ uint64_t vkrhip_exchange_result_words(uint32_t views) { return exchange_result_w
 
 namespace {
 
+// `on`: null = the context's stream, behind a join with the second stream; the
+// second stream itself when the frame's tail was put there (the pack then follows
+// that work in stream order and the context's stream is not held up).
 int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, uint32_t key_cap,
-                          hipEvent_t packed = nullptr) {
+                          hipEvent_t packed = nullptr, hipStream_t on = nullptr) {
   if (!c->frame_ran || !(c->last_stages & VKRHIP_STAGE_CULL))
     return fail(c, VKRHIP_ERR_STATE, "exchange needs a frame that ran the cull stage");
   // with a publication the lists hold rank-local packed row indices, which
@@ -2565,7 +2572,10 @@ int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, 
   if (c->published)
     return fail(c, VKRHIP_ERR_STATE,
                 "the exchange merges source-row indices; it cannot run while a publication is set");
-  TRY(join_side(c));  // the pack reads the frame's sorted keys
+  if (!on) {
+    TRY(join_side(c));  // the pack reads the frame's sorted keys
+    on = c->stream;
+  }
   ExchangePackArgs a{};
   a.states = c->states.p;
   a.visible = c->visible.p;
@@ -2579,7 +2589,7 @@ int enqueue_exchange_pack(vkrhip_ctx *c, uint32_t *block_dev, uint32_t vis_cap, 
   a.have_keys = (c->last_stages & VKRHIP_STAGE_TRANSPARENT) && c->out_keys.p ? 1u : 0u;
   const uint64_t widest = std::max<uint64_t>(std::max(vis_cap, key_cap), 1);
   const unsigned blocks = (unsigned)std::min<uint64_t>(ceil_div(widest, 1024), 512);
-  hipExtLaunchKernelGGL(k_exchange_pack, dim3(blocks, c->views + 1u), dim3(256), 0, c->stream, nullptr,
+  hipExtLaunchKernelGGL(k_exchange_pack, dim3(blocks, c->views + 1u), dim3(256), 0, on, nullptr,
                         packed, 0, a);
   HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
@@ -2693,14 +2703,24 @@ int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, u
   if (c->views == 0) return fail(c, VKRHIP_ERR_STATE, "no views set");
   TRY(bind_device(c));
   if (!c->xstream) {
-    // its few small kernels sit between collectives: highest priority, so they are
-    // dispatched ahead of the next frame's large grids (and from a queue of their own)
-    int least = 0, greatest = 0;
-    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(c, hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, greatest));
+    // Default priority, on purpose. Created with the highest priority (so that its
+    // few small kernels between the collectives would be placed ahead of the next
+    // frame's large grids - which measured no difference), this stream stalled the
+    // whole context once the process held more streams than hardware queues: with
+    // eight streams of default priority and two of high priority alive elsewhere in
+    // the process (PyTorch creates pools of 32 per priority on first use), the third
+    // run of the exchange never finished and even hipStreamQuery on this stream did
+    // not return, whenever the frame's sort ran on the second stream; with this
+    // stream at default priority the same process completes (tools/
+    // exchange_hang_probe.py reproduces both). The stream's first packet per run is
+    // a barrier that waits for the pack on a default-priority queue: a high-priority
+    // queue that holds its hardware slot while it waits for a queue that is not
+    // scheduled is a priority inversion the queue scheduler does not resolve.
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
   }
-  if (!c->x_packed) HIP_TRY(c, hipEventCreateWithFlags(&c->x_packed, hipEventDisableTiming));
+  TRY(join_side(c));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  TRY(drain_side(c));  // (a pack on the second stream writes the blocks that are replaced below)
   HIP_TRY(c, hipStreamSynchronize(c->xstream));
   const uint64_t words = exchange_block_words(c->views, vis_cap, key_cap);
   for (auto &x : c->xset) {
@@ -2710,6 +2730,7 @@ int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, u
     TRY(dev_alloc(c, x.merged_keys, std::max<uint64_t>((uint64_t)world * key_cap, 1)));
     TRY(dev_alloc(c, x.result, exchange_result_words(VKRHIP_MAX_VIEWS)));
     if (!x.done) HIP_TRY(c, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
+    if (!x.packed) HIP_TRY(c, hipEventCreateWithFlags(&x.packed, hipEventDisableTiming));
     x.in_flight = false;
   }
   c->x_world = world;
@@ -2729,12 +2750,24 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
   TRY(bind_device(c));
   const int k = (int)(c->x_turn++ & 1u);
   auto &x = c->xset[k];
+  // Where the frame left work on the second stream (its sort and emission, or its
+  // whole tail), the pack follows it there: the context's stream - the next frame's
+  // transform and classify - then never waits for this frame's lists and keys, nor
+  // for the exchange. Otherwise the pack goes to the context's stream.
+  const bool on_side = second_stream_usable(c) && c->side_last >= 0 && c->side_pending[c->side_last];
+  hipStream_t pack_stream = on_side ? c->tstream : c->stream;
   // the exchange that used this set two frames ago must be done with it
   // (normally long finished: a barrier packet is only queued when it is not)
-  if (x.in_flight && hipEventQuery(x.done) != hipSuccess)
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, x.done, 0));
-  TRY(enqueue_exchange_pack(c, x.send.p, c->x_vis_cap, c->x_key_cap, c->x_packed));
-  HIP_TRY(c, hipStreamWaitEvent(c->xstream, c->x_packed, 0));
+  if (x.in_flight && hipEventQuery(x.done) != hipSuccess) {
+    if (c->xdebug & 16) fprintf(stderr, "[x] run %u: stream %s waits for done[%d]\n", c->x_turn, on_side ? "side" : "main", k);
+    HIP_TRY(c, hipStreamWaitEvent(pack_stream, x.done, 0));
+  }
+  if (c->xdebug & 16) fprintf(stderr, "[x] run %u: pack on %s, set %d\n", c->x_turn, on_side ? "side" : "main", k);
+  TRY(enqueue_exchange_pack(c, x.send.p, c->x_vis_cap, c->x_key_cap, x.packed, on_side ? c->tstream : nullptr));
+  // the batch of second-stream work now ends behind the pack (which reads the
+  // frame's lists, keys and counters): its event is recorded again
+  if (on_side) HIP_TRY(c, hipEventRecord(c->ev_side[c->side_last], c->tstream));
+  HIP_TRY(c, hipStreamWaitEvent(c->xstream, x.packed, 0));
   const uint64_t words = exchange_block_words(c->views, c->x_vis_cap, c->x_key_cap);
   if (c->comm) {
     const int rc = g_rccl.AllGather(x.send.p, x.recv.p, words, kNcclUint32, c->comm, c->xstream);
@@ -2750,12 +2783,47 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
   return VKRHIP_OK;
 }
 
+int vkrhip_debug_streams(vkrhip_ctx *c, int32_t *out, uint32_t n) {
+  if (!c || !out) return VKRHIP_ERR_ARG;
+  int32_t v[10];
+  auto sq = [](hipStream_t s) { return s ? (int32_t)(hipStreamQuery(s) != hipSuccess) : -1; };
+  auto eq = [](hipEvent_t e) { return e ? (int32_t)(hipEventQuery(e) != hipSuccess) : -1; };
+  v[0] = sq(c->stream);
+  v[1] = sq(c->tstream);
+  v[2] = sq(c->xstream);
+  v[3] = eq(c->ev_gathered);
+  v[4] = eq(c->ev_side[0]);
+  v[5] = eq(c->ev_side[1]);
+  v[6] = eq(c->xset[0].packed);
+  v[7] = eq(c->xset[0].done);
+  v[8] = eq(c->xset[1].packed);
+  v[9] = eq(c->xset[1].done);
+  (void)hipGetLastError();
+  for (uint32_t k = 0; k < n && k < 10u; ++k) out[k] = v[k];
+  return VKRHIP_OK;
+}
+
 int vkrhip_exchange_finish(vkrhip_ctx *c, uint64_t *result_out, const uint32_t **merged_visible_dev,
                            const uint64_t **merged_keys_dev) {
   if (!c || !result_out) return VKRHIP_ERR_ARG;
   if (c->x_last < 0) return fail(c, VKRHIP_ERR_STATE, "vkrhip_exchange_run has not been called");
   TRY(bind_device(c));
   auto &x = c->xset[c->x_last];
+  if (c->xdebug & 32) {  // diagnosis: poll instead of blocking, and name what is pending when it stalls
+    for (int tries = 0; hipStreamQuery(c->xstream) != hipSuccess; ++tries) {
+      if (tries > 500) {
+        int32_t v[10];
+        (void)vkrhip_debug_streams(c, v, 10);
+        return fail(c, VKRHIP_ERR_STATE,
+                    "exchange stalled: main %d side %d exchange %d | ev_gathered %d ev_side %d %d | set0 packed %d "
+                    "done %d | set1 packed %d done %d (1 = pending)",
+                    v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+      }
+      struct timespec ts = {0, 1000000};
+      nanosleep(&ts, nullptr);
+    }
+    (void)hipGetLastError();
+  }
   HIP_TRY(c, hipMemcpyAsync(result_out, x.result.p, exchange_result_words(c->views) * 8,
                             hipMemcpyDeviceToHost, c->xstream));
   HIP_TRY(c, hipStreamSynchronize(c->xstream));
