@@ -56,10 +56,18 @@ WORKLOADS = {
 #              (four state buckets, visible blend row)
 #   fused    : both, minus the re-read of world (it is classified in registers)
 def kernel_bytes(name: str, n: int, depth: int, views: int, dirty_local: bool = False,
-                 submeshes: int = 1) -> float:
+                 submeshes: int = 1, moved: int = -1) -> float:
     transform = 64 + 64 + 2 + (4 if depth > 1 else 0)
     if dirty_local:  # TRS 48 in instead of the cached local, rebuilt local 64 out
         transform += 48
+    if 0 <= moved < n and name == "fused":
+        # a node that did not move: its stored world matrix is read (64) instead of the
+        # local one and no matrix is written; flags, parent index and the cull inputs
+        # and outputs move as for any node
+        clean = n - moved
+        per_node_cull = 16 + 4 + 1
+        return (moved * (transform + per_node_cull) + clean * (64 + 2 + (4 if depth > 1 else 0) + per_node_cull)
+                + n * (views + 5) / 8)
 
     # with several rows per transform the matrix is fetched once per node
     classify_in, classify_out = 64 / submeshes + 16 + 4 + (4 if submeshes > 1 else 0), 1
@@ -75,6 +83,30 @@ def kernel_bytes(name: str, n: int, depth: int, views: int, dirty_local: bool = 
 
 KERNEL_NAMES = {"transform": "k_propagate_classify", "classify": "k_classify",
                 "fused": "k_propagate_classify"}
+
+# The vector-instruction roof: a wave64 instruction occupies its 16-lane SIMD for four
+# cycles, so the chip issues at most SIMDs x clock / 4 of them per second
+# (256 CUs x 4 SIMDs x 2.4 GHz / 4).
+VALU_PEAK_INSTS_PER_S = 256 * 4 * 2.4e9 / 4
+
+
+def pmc_valu_insts(workload_name: str, overridden: bool, kernel: str):
+    """SQ_INSTS_VALU per step of the dominant kernel from the committed counter pass
+    of this workload (wave instructions, summed over the kernel's dispatches of one
+    frame), or None."""
+    if overridden:
+        return None, None
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload_name}.json")))
+    if not paths:
+        return None, None
+    with open(paths[-1]) as fh:
+        data = json.load(fh)
+    total = 0.0
+    for name, k in data["kernels"].items():
+        if name.startswith(kernel) and "valu_insts_per_dispatch" in k:
+            total += k["dispatches_per_frame"] * k["valu_insts_per_dispatch"]
+    return (total or None), os.path.relpath(paths[-1], ROOT)
 
 
 def pmc_traffic(workload_name: str, overridden: bool, kernel: str, variant=None):
@@ -158,15 +190,34 @@ class Setup:
         self.hs.close()
 
 
+EXCHANGE_TIMERS = ("exchange_pack", "exchange_gather", "exchange_merge")
+
+
 def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden):
     """Timed frames of one workload. Returns (elapsed seconds, roofline dict, warm-up
-    stage timings, frame info)."""
+    stage timings, frame info, exchange stage timings or None).
+    dirty: "world" every node moved, locals cached; "local" every node's TRS changed;
+    "subtrees" a tenth of the subtrees hanging from hierarchy level 2 moved (another
+    tenth every frame), everything else is clean."""
     from vulkan_renderer_amd import _native as N
+    from vulkan_renderer_amd.parallel import RcclExchange
     hs, sc, workload, n = setup.hs, setup.sc, setup.workload, setup.n
     dirty_bits = N.DIRTY_LOCAL if dirty == "local" else N.DIRTY_WORLD
+    native_exchange = isinstance(exchange, RcclExchange)
+    frame_no = [0]
+    if dirty == "subtrees":
+        lo = sc.level_offsets
+        cut = min(2, len(lo) - 2)
+        cut_first, cut_count = int(lo[cut]), int(lo[cut + 1] - lo[cut])
+        run = max(1, cut_count // 10)
 
     def step():
-        hs.mark_all(dirty_bits)      # every node moved this frame
+        if dirty == "subtrees":      # the roots of the moved subtrees; their descendants follow on the device
+            start = (frame_no[0] * run) % max(cut_count - run + 1, 1)
+            hs.mark_nodes(cut_first + start, run, N.DIRTY_WORLD)
+            frame_no[0] += 1
+        else:
+            hs.mark_all(dirty_bits)  # every node moved this frame
         hs.frame(N.STAGE_ALL)
         if exchange is not None:
             exchange.run()
@@ -191,7 +242,7 @@ def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden)
     for k in range(steps):
         sampled = k % EVENT_STRIDE == 0
         if sampled:
-            hs.set_profiling([dominant])
+            hs.set_profiling([dominant] + (list(EXCHANGE_TIMERS) if native_exchange else []))
         step()
         if sampled:
             hs.set_profiling(False)
@@ -202,7 +253,8 @@ def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden)
 
     dom_ms, dom_n = timers[dominant]
     dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
-    alg_bytes = kernel_bytes(dominant, n, workload["depth"], setup.views, dirty == "local", submeshes)
+    moved = info.nodes_updated if dirty == "subtrees" else -1
+    alg_bytes = kernel_bytes(dominant, n, workload["depth"], setup.views, dirty == "local", submeshes, moved)
     achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
     traffic, traffic_source = pmc_traffic(setup.name, overridden, KERNEL_NAMES[dominant],
                                           {"fused": "true", "transform": "false"}.get(dominant))
@@ -216,8 +268,25 @@ def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden)
         "avg_launch_us": round(dom_avg_s * 1e6, 2), "event_samples": dom_n,
         "algorithmic_bytes_per_step": int(alg_bytes),
     }
+    # the same kernel against the vector-instruction roof (wave instructions per step
+    # from the committed counter pass over the kernel's live duration): whichever
+    # fraction is higher names the bound
+    insts, insts_source = pmc_valu_insts(setup.name, overridden, KERNEL_NAMES[dominant])
+    if insts and dom_avg_s > 0:
+        valu_frac = insts / dom_avg_s / VALU_PEAK_INSTS_PER_S
+        roofline["roofline_valu"] = {
+            "insts_per_step": int(insts), "source": insts_source,
+            "peak_insts_per_s": VALU_PEAK_INSTS_PER_S,
+            "peak_from": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction",
+            "frac": round(valu_frac, 4)}
+        if valu_frac > roofline["frac"]:
+            roofline["bound"] = "valu"
     stage_us = {k: round(v[0] * 1e3 / max(v[1], 1), 2) for k, v in warm.items() if v[1]}
-    return elapsed, roofline, stage_us, info
+    exchange_us = None
+    if native_exchange:
+        exchange_us = {k: round(timers[k][0] * 1e3 / max(timers[k][1], 1), 2) for k in EXCHANGE_TIMERS
+                       if timers[k][1]}
+    return elapsed, roofline, stage_us, info, exchange_us
 
 
 CANDIDATE_ROW_BYTES = 144            # VkrWorldDrawCandidate
@@ -384,9 +453,13 @@ def main() -> int:
     ap.add_argument("--submeshes", type=int, default=1,
                     help="candidate rows per transform (>1: the stand-alone transform and classify "
                          "kernels run instead of the fused one)")
-    ap.add_argument("--dirty", default="world", choices=["world", "local"],
+    ap.add_argument("--dirty", default="world", choices=["world", "local", "subtrees"],
                     help="what moves every frame: world = cached local matrices are re-propagated "
-                         "(default); local = every node's TRS changed, locals are rebuilt too")
+                         "(default); local = every node's TRS changed, locals are rebuilt too; subtrees = a "
+                         "tenth of the subtrees below hierarchy level 2, the rest of the scene is clean")
+    ap.add_argument("--dump-merged", default="",
+                    help="with an exchange: rank 0 writes the merged visible lists, ranges and draw keys of "
+                         "the last frame to this .npz file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the other single-GPU workloads (flat1m, flat32m, probes64)")
@@ -467,12 +540,18 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed, roofline, stage_us, info = measure(setup, args.steps, args.warmup, args.dirty,
-                                                args.submeshes, exchange, fence, overridden)
+    elapsed, roofline, stage_us, info, exchange_us = measure(setup, args.steps, args.warmup, args.dirty,
+                                                             args.submeshes, exchange, fence, overridden)
+    rank_ms = [elapsed * 1e3 / args.steps]
+    rank_frac = [roofline["frac"]]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed, roofline["frac"]], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(e[0]) * 1e3 / args.steps for e in every]
+        rank_frac = [float(e[1]) for e in every]
+        elapsed = max(float(e[0]) for e in every)
     if exchange is not None:
         regrown = exchange.regrown
         try:
@@ -483,6 +562,12 @@ def main() -> int:
         if exchange.regrown != regrown:
             print("bench.py: the exchange blocks overflowed inside the timed region", file=sys.stderr)
             return 3
+        if args.dump_merged and rank == 0:
+            v = views
+            np.savez(args.dump_merged,
+                     vis=exchange.vis_merged.cpu().numpy().view(np.uint32)[: exchange.visible_total],
+                     keys=exchange.key_merged.cpu().numpy().view(np.uint64)[: exchange.transparent_total],
+                     merged_ranges=exchange.merged_ranges, view_offsets=exchange.view_offsets)
 
     ms_per_step = elapsed * 1e3 / args.steps
     total_instances = setup.total  # (the shards of a hierarchy differ by a few nodes)
@@ -504,11 +589,12 @@ def main() -> int:
             "timed_stages": "transform + multi-view cull + compaction + transparent key sort and draw "
                             "emission, outputs left in HBM; the 144-byte candidate rows of "
                             "application_build_world_payload are NOT in it (see dropin)",
-            "streams": ("one (the multi-GPU exchange needs a frame's results right behind it)"
-                        if exchange is not None else
-                        "hierarchies of 4M nodes and more: the transparent sort and emission of a frame "
-                        "run on a second stream beside the next frame's transform (the dominant kernel's "
-                        "event time includes that contention); VKRHIP_OVERLAP_SORT=0 keeps one stream"),
+            "streams": "scenes of 4M nodes and more with up to 8 views: scan, gather, sort and emission of a "
+                       "frame run on a second stream beside the next frame's transform and classify (more "
+                       "views: sort and emission only), so the dominant kernel's event time includes that "
+                       "contention; VKRHIP_OVERLAP_TAIL=0 / VKRHIP_OVERLAP_SORT=0 keep one stream"
+                       + ("; the exchange's pack follows the tail on the second stream, all-gather and merge "
+                          "run on a third" if exchange is not None else ""),
             "exchange": ("one all-gather of packed blocks (visible lists + draw-key runs), "
                          "device-planned merge, overlapped with the next frame") if exchange is not None else "none",
         },
@@ -517,6 +603,29 @@ def main() -> int:
                                   / HBM_PEAK_GBS, 4),
         "stage_us_warmup": stage_us,
     }
+    if exchange is not None:
+        from vulkan_renderer_amd.parallel import exchange_block_words
+        ranks_rccl = None
+        if getattr(exchange, "scene", None) is not None and world > 1:
+            try:
+                ranks_rccl = hs.comm_count()
+            except Exception:
+                ranks_rccl = None
+        result["config"]["ranks_seen"] = {
+            "torch_distributed": dist.get_world_size() if world > 1 else 1,
+            "rccl_communicator": ranks_rccl,
+            "transport": "rccl (library)" if ranks_rccl else
+                         ("none (one rank)" if world == 1 else f"torch.distributed/{args.backend}")}
+        result["ms_per_step_ranks"] = {"min": min(rank_ms), "max": max(rank_ms)}
+        result["roofline_frac_ranks"] = {"min": min(rank_frac), "max": max(rank_frac)}
+        result["exchange"] = {
+            "bytes_per_rank": 4 * exchange_block_words(views, exchange.vis_cap, exchange.key_cap),
+            "us_pack": (exchange_us or {}).get("exchange_pack"),
+            "us_allgather": (exchange_us or {}).get("exchange_gather"),
+            "us_merge": (exchange_us or {}).get("exchange_merge"),
+            "timed": "HIP events around the stages on the streams they run on (rank 0), in one of every "
+                     f"{EVENT_STRIDE} timed steps; null: not timed (torch-driven exchange) or absent (one rank "
+                     "has no all-gather)"}
 
     single = rank == 0 and world == 1
     want_capacity = False
@@ -537,15 +646,24 @@ def main() -> int:
     if single and not args.no_secondary and not overridden and exchange is None:
         # the other single-GPU configurations, each with its own roofline (shorter runs)
         secondary = []
-        for name in ("flat1m", "flat32m", "probes64", "deep16m"):
-            if name == args.workload:
-                continue
+        moved_text = {"world": "every node: world matrices re-propagated from cached locals",
+                      "local": "every node's TRS changed: local matrices rebuilt as well (48 B/node more in, "
+                               "64 B/node more out)",
+                      "subtrees": "a tenth of the subtrees below hierarchy level 2 (another tenth every frame); "
+                                  "clean nodes read their stored world matrix and write none"}
+        runs = [(name, "world") for name in ("flat1m", "flat32m", "probes64", "deep16m") if name != args.workload]
+        runs += [(args.workload, "local")]
+        if WORKLOADS[args.workload]["depth"] > 2:
+            runs += [(args.workload, "subtrees")]
+        for name, dirty in runs:
             other = Setup(name, dict(WORKLOADS[name]), 0, local_rank, args.seed, 1)
             steps = max(10, args.steps // 2)
-            el, roof, _, inf = measure(other, steps, max(3, args.warmup // 2), "world", 1, None, fence, False)
+            el, roof, _, inf, _ = measure(other, steps, max(3, args.warmup // 2), dirty, 1, None, fence,
+                                          dirty != "world")
             secondary.append({
                 "workload": f"{name}: {WORKLOADS[name]['desc']}", "instances_per_gpu": other.n,
                 "views": other.views, "steps": steps, "ms_per_step": el * 1e3 / steps,
+                "moved_per_frame": moved_text[dirty], "nodes_updated": inf.nodes_updated,
                 "value": other.n * steps / el, "roofline": roof,
                 "whole_frame_frac": round(roof["algorithmic_bytes_per_step"] / (el / steps) / 1e9
                                           / HBM_PEAK_GBS, 4),
@@ -589,6 +707,7 @@ def cpu_baseline(sc, planes, required, vs, budget_s: float) -> dict:
             break
     o.baseline_destroy(h)
     out = {"value": sample * frames / dt, "unit": "instances/s", "cores": 1, "kind": "port",
+           "host": host_description(),
            "sample": f"{frames} frames of " + ("the first " if flat else "all ") +
                      f"{sample} instances of the workload, all {planes.shape[0]} views, {dt:.1f} s; "
                      "includes the 144-byte candidate emission of application_build_world_payload "
@@ -596,7 +715,81 @@ def cpu_baseline(sc, planes, required, vs, budget_s: float) -> dict:
     if flat:
         out["all_cores"] = cpu_baseline_all_cores(o, sc, sample, local, planes, required, vs,
                                                   min(10.0, budget_s))
+    else:
+        out["all_cores"] = cpu_baseline_all_cores_sharded(o, sc, local, planes, required, vs,
+                                                          min(10.0, budget_s))
     return out
+
+
+def host_description() -> dict:
+    """The box the CPU figures were taken on: CPU model and logical CPUs as the
+    kernel reports them, and the share this process may use."""
+    model, logical = None, 0
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    logical += 1
+                    if model is None:
+                        model = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"model": model, "nproc": logical or (os.cpu_count() or 1), "usable_by_this_process": usable,
+            "threads_env": os.environ.get("OMP_NUM_THREADS")}
+
+
+def cpu_baseline_all_cores_sharded(o, sc, local, planes, required, vs, budget_s: float) -> dict:
+    """Not in the reference (its path runs on the render thread alone): the hierarchy
+    cut into one shard of whole subtrees per host thread (vkrhip_shard_hierarchy, the
+    cut the multi-GPU path uses; levels above the cut are replicated), every thread
+    looping over its own shard with the single-thread loop, no merge of the results."""
+    import threading
+    from vulkan_renderer_amd.scene import shard_hierarchy, shard_local_hierarchy
+    threads = max(1, min(16, os.cpu_count() or 1))
+    levels = len(sc.level_offsets) - 1
+    # the first level that holds at least four subtrees per thread
+    cut = next((l for l in range(levels) if sc.level_offsets[l + 1] - sc.level_offsets[l] >= 4 * threads),
+               levels - 1)
+    ranges = shard_hierarchy(sc.parent, sc.level_offsets, threads, replicated_levels=cut)
+    frames = [0] * threads
+    handles = [None] * threads
+    sizes = [0] * threads
+    start = threading.Barrier(threads + 1)
+    stop_at = [0.0]
+
+    def work(k):
+        nodes, parent_k, _ = shard_local_hierarchy(sc.parent, ranges[k])
+        idx = nodes.astype(np.int64)
+        sizes[k] = int(idx.shape[0])
+        handles[k] = o.baseline_create(parent_k, local[idx], None, sc.ident[idx], sc.matbits[idx],
+                                       sc.bounds[idx], planes, required, vs.view, vs.projection)
+        o.baseline_frame(handles[k])  # warm
+        start.wait()
+        while time.perf_counter() < stop_at[0]:
+            o.baseline_frame(handles[k])
+            frames[k] += 1
+
+    pool = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    for t in pool:
+        t.start()
+    stop_at[0] = float("inf")
+    start.wait()
+    t0 = time.perf_counter()
+    stop_at[0] = t0 + budget_s
+    for t in pool:
+        t.join()
+    dt = time.perf_counter() - t0
+    for h in handles:
+        o.baseline_destroy(h)
+    done = sum(f * n for f, n in zip(frames, sizes))
+    return {"value": done / dt, "unit": "instances/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} threads, one shard of whole subtrees each (cut at hierarchy level {cut}, "
+                      f"{min(sizes)}..{max(sizes)} nodes per shard, {sum(frames)} shard frames), no merge, "
+                      f"{dt:.1f} s; not in the reference"}
 
 
 def cpu_baseline_all_cores(o, sc, sample, local, planes, required, vs, budget_s: float) -> dict:

@@ -223,6 +223,12 @@ int vkrhip_upload_node_flags(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
                              const uint8_t *flags);
 /* OR `flags` into every node (e.g. VKRHIP_DIRTY_WORLD: everything moved). */
 int vkrhip_mark_all(vkrhip_ctx *ctx, uint8_t flags);
+/* OR `flags` into nodes [first, first + count), on the device and in stream order
+ * (no host wait): what the reference's transform setters do for one transform
+ * (vkr_scene_system.h:70-72), for a run of nodes - e.g. the roots of the subtrees
+ * that moved this frame; their descendants follow by the deferred propagation of
+ * vkr_scene_update (vkr_scene_system.c:1310-1316). */
+int vkrhip_mark_nodes(vkrhip_ctx *ctx, uint64_t first, uint64_t count, uint8_t flags);
 
 /* ---- candidate source rows: the (instance, submesh) enumeration of
  * application_build_world_payload (lib/src/application.h:730-806) -----------
@@ -337,7 +343,10 @@ int vkrhip_read_candidate_prep(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
 #define VKRHIP_TIMER_EMIT 6
 #define VKRHIP_TIMER_CANDIDATES 7
 #define VKRHIP_TIMER_FRAME 8
-#define VKRHIP_TIMER_COUNT 9
+#define VKRHIP_TIMER_EXCHANGE_PACK 9    /* vkrhip_exchange_run: the pack kernel */
+#define VKRHIP_TIMER_EXCHANGE_GATHER 10 /* ... the all-gather (with a communicator) */
+#define VKRHIP_TIMER_EXCHANGE_MERGE 11  /* ... plan + merge kernels */
+#define VKRHIP_TIMER_COUNT 12
 /* timer_mask: bit VKRHIP_TIMER_x set = bracket that stage with HIP events; 0 = off. */
 int vkrhip_set_profiling(vkrhip_ctx *ctx, uint32_t timer_mask);
 /* Accumulated milliseconds and sample counts since the last reset; waits for
@@ -467,6 +476,8 @@ uint32_t vkrhip_levelize(const uint32_t *parent, uint64_t n, uint32_t *order,
  * lists stay valid until the run after the next one. */
 int vkrhip_comm_unique_id(uint8_t *out_id128);
 int vkrhip_comm_init(vkrhip_ctx *ctx, const uint8_t *id128, uint32_t world, uint32_t rank);
+/* Ranks the context's communicator spans, as RCCL itself reports them (ncclCommCount). */
+int vkrhip_comm_count(vkrhip_ctx *ctx, uint32_t *out_ranks);
 int vkrhip_exchange_configure(vkrhip_ctx *ctx, uint32_t world, uint32_t vis_cap, uint32_t key_cap);
 int vkrhip_exchange_run(vkrhip_ctx *ctx);
 int vkrhip_exchange_finish(vkrhip_ctx *ctx, uint64_t *result_out,

@@ -453,3 +453,70 @@ def test_overflow_after_the_scene_advanced_is_not_repeated(oracle):
         ex.run()            # the newer frame's own exchange sizes the blocks
         ex.finish()
         assert ex.regrown == 1
+
+
+@pytest.mark.parametrize("workload,n", [("deep16m", 200000), ("flat32m", 150000)])
+def test_bench_two_ranks_one_gpu(oracle, tmp_path, workload, n):
+    """bench.py --gpus 2 as two fresh processes on this GPU (collective over gloo):
+    the line rank 0 prints, and the merged lists and draw keys it leaves behind
+    against the CPU oracle on the UNSHARDED scene. A hierarchy's rows are numbered
+    shard after shard, so its lists are compared as sets per (view, bucket) after
+    the renumbering; a flat scene keeps its numbering and is compared as it is."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import oracle_frame, view_set
+    from vulkan_renderer_amd import synth
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world, port, dump = 2, _free_port(), str(tmp_path / "merged.npz")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo",
+             "--workload", workload, "--instances", str(n), "--steps", "3", "--warmup", "2",
+             "--no-cpu-baseline", "--dump-merged", dump],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    spec = bench.WORKLOADS[workload]
+    vs = synth.camera_views(cascades=spec["cascades"])
+    planes, required = view_set(vs)
+    if spec["depth"] > 1:
+        whole = synth.deep_scene(n * world, depth=spec["depth"], seed=2)
+        new_id = np.zeros(whole.n, np.uint64)
+        total = 0
+        for r in range(world):
+            shard = synth.sharded_deep_scene(n, world, r, depth=spec["depth"], seed=2)
+            nodes = shard.meta["global_nodes"].astype(np.int64)
+            new_id[nodes] = shard.meta["index_base"] + np.arange(nodes.shape[0], dtype=np.uint64)
+            total = shard.meta["total"]
+    else:
+        whole = synth.flat_scene(n * world, seed=1)
+        new_id = np.arange(whole.n, dtype=np.uint64)
+        total = whole.n
+    assert line["n_gpus"] == world and line["config"]["instances_total"] == total
+    assert line["config"]["ranks_seen"]["torch_distributed"] == world
+    assert line["ms_per_step_ranks"]["max"] >= line["ms_per_step_ranks"]["min"] > 0
+    assert line["roofline"]["frac"] > 0 and line["exchange"]["bytes_per_rank"] > 0
+    ref = oracle_frame(oracle, whole, planes, required, vs.view, vs.projection)
+    got = np.load(dump)
+    for v in range(planes.shape[0]):
+        st = ref["states"][v]
+        assert (got["merged_ranges"][v][:, 1] == st["execution_ranges"][:, 1]).all(), f"view {v} counts"
+        for b in range(4):
+            off, cnt = (int(x) for x in st["execution_ranges"][b])
+            want = new_id[ref["visible"][v, off: off + cnt].astype(np.int64)]
+            goff = int(got["view_offsets"][v]) + int(got["merged_ranges"][v][b][0])
+            have = got["vis"][goff: goff + cnt].astype(np.uint64)
+            assert (np.diff(have.astype(np.int64)) > 0).all(), f"view {v} bucket {b} not ascending"
+            assert (np.sort(want) == have).all(), f"view {v} bucket {b}"
+    keys = ref["payload"]["sort_keys"]
+    want = (keys & np.uint64(0xFFFFFFFF00000000)) | (new_id[(keys & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1]
+                                                      + np.uint64(1))
+    assert got["keys"].shape == want.shape and (np.diff(got["keys"].astype(np.float64)) <= 0).all()
+    assert (np.sort(got["keys"]) == np.sort(want)).all(), "merged draw keys"

@@ -157,6 +157,36 @@ def test_dirty_propagation(oracle, staged_mode, tail_mode):
         assert_bits_equal(hs.read_world(), world1, "after mark_all")
 
 
+def test_mark_nodes_moves_whole_subtrees(oracle):
+    """vkrhip_mark_nodes: DIRTY_WORLD set on the device for a run of nodes of one
+    level; their descendants follow by deferred propagation, everything else stays
+    clean (flags, world matrices and the length of the render-dirty list against
+    the oracle with the same flags set on the host). Two frames in a row, the second
+    with another run, without a host wait in between."""
+    synth = _synth()
+    sc = synth.deep_scene(60000, depth=6, seed=31, fanout=5, roots=6)
+    vs = synth.camera_views(cascades=1)
+    planes, required = view_set(vs)
+    with hip_scene_for(sc, planes.shape[0]) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+        compare_frame(hs, ref, sc)
+        local, world, flags = ref["local"], ref["world"], ref["flags"]
+        lo = sc.level_offsets
+        for first, count in ((int(lo[2]) + 3, 17), (int(lo[1]) + 1, 2)):
+            hs.mark_nodes(first, count, DIRTY_WORLD)
+            hs.frame()
+            flags = flags.copy()
+            flags[first: first + count] |= DIRTY_WORLD
+            _, world, flags, dirty = oracle.scene_update(sc.parent, local=local, flags=flags, world=world)
+        info = hs.frame_info()
+        assert info.nodes_updated == dirty.shape[0] and 0 < dirty.shape[0] < sc.n
+        assert_bits_equal(hs.read_world(), world, "world matrices")
+        assert (hs.read_node_flags() == flags).all()
+        assert hs.lib.vkrhip_mark_nodes(hs.ctx, sc.n, 1 << 40, DIRTY_WORLD) != 0  # beyond the capacity
+
+
 def test_uploaded_locals_and_unordered_hierarchy(oracle):
     """Arbitrary parent array -> levelize -> propagate, against the oracle's BFS."""
     from vulkan_renderer_amd import HipScene, levelize

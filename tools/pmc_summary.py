@@ -57,6 +57,11 @@ def main() -> int:
                     "fetch_bytes_per_dispatch_x2": 2 * 1024.0 * f_total / max(f_n, 1),
                     "write_bytes_per_dispatch": 1024.0 * w_total / max(w_n, 1),
                 }
+                for counter, key in (("SQ_INSTS_VALU", "valu_insts_per_dispatch"),
+                                     ("SQ_INSTS_SALU", "salu_insts_per_dispatch")):
+                    if counter in acc[k]:  # wave instructions, all shader engines summed
+                        total, n = acc[k][counter]
+                        out["kernels"][k][key] = total / max(n, 1)
         with open(sys.argv[3], "w") as fh:
             json.dump(out, fh, indent=1)
     return 0

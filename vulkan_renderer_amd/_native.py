@@ -30,12 +30,12 @@ STAGE_CASTER_BOUNDS = 0x80
 STAGE_ALL = 0x7
 
 TIMER_NAMES = ["transform", "classify", "fused", "scan", "scatter", "sort", "emit",
-               "candidates", "frame"]
+               "candidates", "frame", "exchange_pack", "exchange_gather", "exchange_merge"]
 
 EXPORTED_SYMBOLS = [
     "vkrhip_create", "vkrhip_destroy", "vkrhip_last_error", "vkrhip_set_stream", "vkrhip_get_stream", "vkrhip_join", "vkrhip_sync",
     "vkrhip_set_hierarchy", "vkrhip_upload_trs", "vkrhip_upload_locals", "vkrhip_upload_worlds",
-    "vkrhip_upload_node_flags", "vkrhip_mark_all", "vkrhip_set_candidates", "vkrhip_set_views",
+    "vkrhip_upload_node_flags", "vkrhip_mark_all", "vkrhip_mark_nodes", "vkrhip_set_candidates", "vkrhip_set_views",
     "vkrhip_frame", "vkrhip_get_frame_info", "vkrhip_get_device_outputs", "vkrhip_read_world",
     "vkrhip_read_locals", "vkrhip_read_node_flags", "vkrhip_read_visible",
     "vkrhip_read_transparent_visible", "vkrhip_read_transparent", "vkrhip_read_candidates",
@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_read_packed", "vkrhip_read_visible_rows", "vkrhip_read_commands", "vkrhip_set_profiling",
     "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_exchange_block_words", "vkrhip_exchange_result_words", "vkrhip_exchange_pack",
-    "vkrhip_exchange_merge", "vkrhip_comm_unique_id", "vkrhip_comm_init", "vkrhip_exchange_configure",
+    "vkrhip_exchange_merge", "vkrhip_comm_unique_id", "vkrhip_comm_init", "vkrhip_comm_count", "vkrhip_exchange_configure",
     "vkrhip_exchange_run", "vkrhip_exchange_finish", "vkrhip_debug_streams", "vkrhip_candidate_epoch", "vkrhip_set_hzb", "vkrhip_build_hzb", "vkrhip_read_hzb", "vkrhip_read_transmission_candidates",
     "vkrhip_frustum_from_view_projection", "vkrhip_mat4_mul", "vkrhip_build_view_set",
     "vkrhip_levelize", "vkrhip_effective_visibility",
@@ -271,6 +271,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_concat_ranges.argtypes = [vp, vp, vp, vp, u32]
     L.vkrhip_comm_unique_id.argtypes = [vp]
     L.vkrhip_comm_init.argtypes = [vp, vp, u32, u32]
+    L.vkrhip_comm_count.argtypes = [vp, vp]
+    L.vkrhip_mark_nodes.argtypes = [vp, u64, u64, C.c_uint8]
+    L.vkrhip_debug_streams.argtypes = [vp, vp, u32]
     L.vkrhip_exchange_configure.argtypes = [vp, u32, u32, u32]
     L.vkrhip_exchange_run.argtypes = [vp]
     L.vkrhip_exchange_finish.argtypes = [vp, vp, vp, vp]

@@ -36,20 +36,16 @@ struct TransformArgs {
   uint32_t force;  // flag bits OR-ed into every node first (bulk "everything moved")
 };
 
-__global__ __launch_bounds__(256) void k_or_flags(uint8_t *flags, uint64_t n, uint8_t bits) {
-  // 16 flag bytes per thread
-  const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
-  if (i + 16u <= n) {
-    uint4 v = *reinterpret_cast<uint4 *>(flags + i);
-    const uint32_t b = bits * 0x01010101u;
-    v.x |= b;
-    v.y |= b;
-    v.z |= b;
-    v.w |= b;
-    *reinterpret_cast<uint4 *>(flags + i) = v;
-  } else {
-    for (uint64_t k = i; k < n; ++k) flags[k] |= bits;
-  }
+// ORs `bits` into the flag byte of nodes [first, first + count) in both copies of
+// the flags (the transform setters of the reference mark single transforms dirty,
+// vkr_scene_system.h:70-72; this is the same for a run of nodes, on the device, in
+// stream order).
+__global__ __launch_bounds__(256) void k_or_flags(uint8_t *flags_a, uint8_t *flags_b, uint64_t first,
+                                                  uint64_t count, uint8_t bits) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  flags_a[first + i] |= bits;
+  flags_b[first + i] |= bits;
 }
 
 }  // namespace vkr

@@ -347,6 +347,7 @@ struct RcclApi {
   int (*AllGather)(const void *send, void *recv, size_t count, int datatype, void *comm,
                    hipStream_t stream) = nullptr;
   int (*CommDestroy)(void *comm) = nullptr;
+  int (*CommCount)(void *comm, int *count) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   bool tried = false, ok = false;
 };
@@ -368,6 +369,7 @@ bool load_rccl() {
   g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(lib, "ncclCommCount"));
   g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllGather && g_rccl.CommDestroy;
   return g_rccl.ok;
 }
@@ -1046,6 +1048,18 @@ int vkrhip_mark_all(vkrhip_ctx *c, uint8_t flags) {
   if (!c) return VKRHIP_ERR_ARG;
   // folded into the next transform launch instead of a separate pass over flags[]
   c->force_flags |= flags;
+  return VKRHIP_OK;
+}
+
+int vkrhip_mark_nodes(vkrhip_ctx *c, uint64_t first, uint64_t count, uint8_t flags) {
+  if (!c) return VKRHIP_ERR_ARG;
+  TRY(check_range(c, first, count, c->cfg.max_nodes, "mark_nodes"));
+  if (count == 0 || flags == 0) return VKRHIP_OK;
+  TRY(bind_device(c));
+  // (both copies, like the uploads: a frame reads one and writes the other)
+  hipLaunchKernelGGL(k_or_flags, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, c->stream,
+                     c->flags2[0].p, c->flags2[1].p, first, count, flags);
+  HIP_TRY(c, hipGetLastError());
   return VKRHIP_OK;
 }
 
@@ -2695,6 +2709,19 @@ int vkrhip_comm_init(vkrhip_ctx *c, const uint8_t *id128, uint32_t world, uint32
   return VKRHIP_OK;
 }
 
+int vkrhip_comm_count(vkrhip_ctx *c, uint32_t *out_ranks) {
+  if (!c || !out_ranks) return VKRHIP_ERR_ARG;
+  *out_ranks = 0;
+  if (!c->comm) return fail(c, VKRHIP_ERR_STATE, "the context has no communicator");
+  if (!g_rccl.CommCount) return fail(c, VKRHIP_ERR_STATE, "ncclCommCount is not available");
+  int n = 0;
+  const int rc = g_rccl.CommCount(c->comm, &n);
+  if (rc != 0)
+    return fail(c, VKRHIP_ERR_HIP, "ncclCommCount failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+  *out_ranks = (uint32_t)n;
+  return VKRHIP_OK;
+}
+
 int vkrhip_exchange_configure(vkrhip_ctx *c, uint32_t world, uint32_t vis_cap, uint32_t key_cap) {
   if (!c || world == 0 || world > 64) return VKRHIP_ERR_ARG;
   if (c->comm ? world != c->comm_world : world != 1)
@@ -2763,21 +2790,28 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
     HIP_TRY(c, hipStreamWaitEvent(pack_stream, x.done, 0));
   }
   if (c->xdebug & 16) fprintf(stderr, "[x] run %u: pack on %s, set %d\n", c->x_turn, on_side ? "side" : "main", k);
-  TRY(enqueue_exchange_pack(c, x.send.p, c->x_vis_cap, c->x_key_cap, x.packed, on_side ? c->tstream : nullptr));
+  {
+    StageTimer timer(c, VKRHIP_TIMER_EXCHANGE_PACK, pack_stream);
+    TRY(enqueue_exchange_pack(c, x.send.p, c->x_vis_cap, c->x_key_cap, x.packed, on_side ? c->tstream : nullptr));
+  }
   // the batch of second-stream work now ends behind the pack (which reads the
   // frame's lists, keys and counters): its event is recorded again
   if (on_side) HIP_TRY(c, hipEventRecord(c->ev_side[c->side_last], c->tstream));
   HIP_TRY(c, hipStreamWaitEvent(c->xstream, x.packed, 0));
   const uint64_t words = exchange_block_words(c->views, c->x_vis_cap, c->x_key_cap);
   if (c->comm) {
+    StageTimer timer(c, VKRHIP_TIMER_EXCHANGE_GATHER, c->xstream);
     const int rc = g_rccl.AllGather(x.send.p, x.recv.p, words, kNcclUint32, c->comm, c->xstream);
     if (rc != 0)
       return fail(c, VKRHIP_ERR_HIP, "ncclAllGather failed: %s",
                   g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
   }
   // without a communicator the world is this rank: its own block is the gathered buffer
-  TRY(enqueue_exchange_merge(c, c->comm ? x.recv.p : x.send.p, c->x_world, c->x_vis_cap, c->x_key_cap,
-                             x.merged_visible.p, x.merged_keys.p, x.result.p, c->xstream, x.done));
+  {
+    StageTimer timer(c, VKRHIP_TIMER_EXCHANGE_MERGE, c->xstream);
+    TRY(enqueue_exchange_merge(c, c->comm ? x.recv.p : x.send.p, c->x_world, c->x_vis_cap, c->x_key_cap,
+                               x.merged_visible.p, x.merged_keys.p, x.result.p, c->xstream, x.done));
+  }
   x.in_flight = true;
   c->x_last = k;
   return VKRHIP_OK;

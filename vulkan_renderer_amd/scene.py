@@ -200,6 +200,10 @@ class HipScene:
     def mark_all(self, flags: int = N.DIRTY_WORLD) -> None:
         self._ok(self.lib.vkrhip_mark_all(self.ctx, flags))
 
+    def mark_nodes(self, first: int, count: int, flags: int = N.DIRTY_WORLD) -> None:
+        """ORs `flags` into nodes [first, first + count) on the device, in stream order."""
+        self._ok(self.lib.vkrhip_mark_nodes(self.ctx, first, count, flags))
+
     # ---- candidates / views --------------------------------------------
     def set_candidates(self, node, ident, matbits, bounds) -> None:
         ident = N.as_u32(ident).reshape(-1, 8)
@@ -420,6 +424,12 @@ class HipScene:
         uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
         assert uid.shape == (128,)
         self._ok(self.lib.vkrhip_comm_init(self.ctx, N.ptr(uid), world, rank))
+
+    def comm_count(self) -> int:
+        """Ranks of the context's RCCL communicator as RCCL reports them."""
+        out = C.c_uint32(0)
+        self._ok(self.lib.vkrhip_comm_count(self.ctx, C.byref(out)))
+        return int(out.value)
 
     def exchange_configure(self, world: int, vis_cap: int, key_cap: int) -> None:
         self._ok(self.lib.vkrhip_exchange_configure(self.ctx, world, vis_cap, key_cap))
