@@ -97,6 +97,54 @@ def test_static_merge_matches_twice_the_second_call_smaller():
             hs.close()
 
 
+def test_static_merge_allocates_nothing_and_is_capturable():
+    """What the entry point is for: after vkrhip_static_init the call leaves the
+    device's free memory as it found it, and it can be made while its stream is
+    being captured into a HIP graph (where an allocation would break the capture);
+    the replayed graph writes the same outputs as the eager call."""
+    import torch
+    from vulkan_renderer_amd import _native as N
+    lib = N.load()
+    dev = torch.cuda.current_device()
+    assert lib.vkrhip_static_init(dev) == N.OK
+    shards, gathered, views, vis_cap, key_cap = _gathered_blocks(world=2, cascades=1, n=20000, seed=13)
+    try:
+        world = len(shards)
+        res_words = shards[0].exchange_result_words(views)
+        vis = torch.full((world * vis_cap,), GUARD, dtype=torch.int32, device="cuda")
+        keys = torch.full((world * key_cap,), GUARD, dtype=torch.int64, device="cuda")
+        res = torch.full((res_words,), GUARD, dtype=torch.int64, device="cuda")
+
+        def call(stream):
+            rc = lib.vkrhip_exchange_merge_static(dev, views, gathered.data_ptr(), world, vis_cap, key_cap,
+                                                  vis.data_ptr(), keys.data_ptr(), res.data_ptr(), stream)
+            assert rc == N.OK, lib.vkrhip_last_error(None)
+
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        call(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free_before, "device memory was allocated"
+        eager = (vis.cpu().numpy().copy(), keys.cpu().numpy().copy(), res.cpu().numpy().copy())
+        assert int(eager[2][0]) == 0 and eager[2][3] > 100
+
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            call(torch.cuda.current_stream().cuda_stream)  # the capturing stream
+        for t in (vis, keys, res):
+            t.fill_(GUARD)
+        torch.cuda.synchronize()
+        assert (vis.cpu().numpy() == np.int32(GUARD)).all()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert (vis.cpu().numpy() == eager[0]).all(), "merged visible lists from the replayed graph"
+        assert (keys.cpu().numpy() == eager[1]).all(), "merged draw keys from the replayed graph"
+        assert (res.cpu().numpy() == eager[2]).all(), "result words from the replayed graph"
+    finally:
+        for hs in shards:
+            hs.close()
+
+
 def test_static_merge_limits():
     import torch
     from vulkan_renderer_amd import _native as N
