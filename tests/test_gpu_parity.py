@@ -411,6 +411,32 @@ def test_rows_must_name_nodes_of_the_scene(oracle):
         hs.frame()
 
 
+def test_hierarchy_shrinks_and_grows_back(oracle):
+    """The flags of nodes outside the bound hierarchy read the same whichever of the
+    two flag copies is current: after the scene shrinks and an odd number of frames
+    has run, the nodes beyond it still show what the last frame that covered them
+    left (WORLD_UPDATED), and when the scene grows back they are not recomputed
+    from stale dirty bits - matrices uploaded for them meanwhile stay."""
+    synth = _synth()
+    sc = synth.deep_scene(3000, depth=4, seed=12, fanout=6, roots=5)
+    n, small = sc.n, int(sc.level_offsets[2])
+    with hip_scene_for(sc, 1) as hs:
+        hs.frame(STAGE_TRANSFORM)
+        assert (hs.read_node_flags() == WORLD_UPDATED).all()
+        hs.set_hierarchy(sc.parent[:small], sc.level_offsets[:3])
+        hs.frame(STAGE_TRANSFORM)  # one frame: the other flag copy is current now
+        flags = hs.read_node_flags(0, n)
+        assert (flags[:small] == 0).all() and (flags[small:n] == WORLD_UPDATED).all()
+        placed = hs.read_world(small, n - small)
+        placed[:, 12:15] += np.float32(7.0)
+        hs.upload_worlds(placed, first=small)
+        hs.set_hierarchy(sc.parent, sc.level_offsets)
+        hs.frame(STAGE_TRANSFORM)
+        assert hs.frame_info().nodes_updated == 0
+        assert (hs.read_node_flags() == 0).all()
+        assert_bits_equal(hs.read_world()[small:], placed, "matrices uploaded while the scene was small")
+
+
 @pytest.mark.parametrize("top_levels", ["1", "0"])
 @pytest.mark.parametrize("dirty", ["all", "subset"])
 def test_merged_top_levels_on_and_off(oracle, monkeypatch, top_levels, dirty):

@@ -205,6 +205,13 @@ def test_shard_hierarchy_refuses_other_numberings():
     with pytest.raises(N.VkrHipError) as e:
         shard_hierarchy(parent, np.array([0, 2, 5], np.uint64), 2)
     assert e.value.code == N.ERR_STATE
+    # level offsets that do not ascend, or run past the node count, are refused
+    # before anything is indexed by them
+    parent = np.array([0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 1], np.uint32)
+    for offsets in ([0, 9, 5], [0, 4, 2, 5], [0, 1 << 40, 5]):
+        with pytest.raises(N.VkrHipError) as e:
+            shard_hierarchy(parent, np.array(offsets, np.uint64), 2)
+        assert e.value.code == N.ERR_ARG
 
 
 def test_sharded_deep_scene_is_the_whole_scene_cut_at_the_roots():

@@ -945,6 +945,15 @@ int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
+  if (n_nodes != c->n_nodes) {
+    // A frame rewrites the flags of the bound nodes only (one copy read, the other
+    // written): the nodes that enter or leave the hierarchy here are current in the
+    // copy in use and must read the same in the other one from now on.
+    const uint64_t from = std::min(n_nodes, c->n_nodes);
+    const uint64_t upto = std::max(n_nodes, c->n_nodes);
+    HIP_TRY(c, hipMemcpyAsync(c->flags_other() + from, c->flags() + from, upto - from,
+                              hipMemcpyDeviceToDevice, c->stream));
+  }
   c->n_nodes = n_nodes;
   c->level_offsets = lo;
   c->top_levels = 0;
@@ -2639,9 +2648,14 @@ void launch_exchange_merge(const ExchangeTables &t, uint32_t views, const uint32
   // copy rows: enough blocks per descriptor to cover the largest possible range
   const unsigned rows = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vis_cap, 4096), 1), 64);
   const unsigned key_blocks = (unsigned)ceil_div((uint64_t)world * key_cap, 256);
-  hipExtLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
-                        nullptr, done, 0, gathered_dev, (const uint64_t *)t.desc, pairs * world, rows,
-                        merged_visible_dev, (const uint64_t *)t.runs, world, merged_keys_dev);
+  if (done)
+    hipExtLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
+                          nullptr, done, 0, gathered_dev, (const uint64_t *)t.desc, pairs * world, rows,
+                          merged_visible_dev, (const uint64_t *)t.runs, world, merged_keys_dev);
+  else  // (a plain launch: also what a stream under graph capture records)
+    hipLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
+                       gathered_dev, (const uint64_t *)t.desc, pairs * world, rows, merged_visible_dev,
+                       (const uint64_t *)t.runs, world, merged_keys_dev);
 }
 
 int enqueue_exchange_merge(vkrhip_ctx *c, const uint32_t *gathered_dev, uint32_t world,

@@ -188,6 +188,9 @@ int vkrhip_shard_hierarchy(const uint32_t *parent, uint64_t n, const uint64_t *l
                            uint64_t *out_ranges) {
   if (!level_offsets || !out_ranges || levels == 0 || shards == 0) return VKRHIP_ERR_ARG;
   if (level_offsets[0] != 0 || level_offsets[levels] != n) return VKRHIP_ERR_ARG;
+  // (ascending, hence all within [0, n]: everything below indexes by them)
+  for (uint32_t l = 0; l < levels; ++l)
+    if (level_offsets[l] > level_offsets[l + 1]) return VKRHIP_ERR_ARG;
   if (levels > 1 && !parent) return VKRHIP_ERR_ARG;
   const uint32_t cut = replicated_levels < levels ? replicated_levels : levels;
   // subtrees are contiguous per level only when parents ascend with their children
