@@ -68,6 +68,7 @@ extern "C" {
 #define VKRHIP_STAGE_PACK 0x20u   /* vkr_vk_pack_gpu_candidates, vkr_vulkan_draws.c:344-428 */
 #define VKRHIP_STAGE_ENCODE 0x40u /* visible rows + indirect commands, deferred.slang:379-420 */
 #define VKRHIP_STAGE_CASTER_BOUNDS 0x80u /* box of the shadow casters, for VkrShadowSceneBounds */
+#define VKRHIP_STAGE_DIRTY_LIST 0x100u /* scene->render_dirty_list, vkr_scene_system.c:458-479,1335 */
 #define VKRHIP_STAGE_ALL 0x7u
 
 typedef struct vkrhip_ctx vkrhip_ctx;
@@ -152,6 +153,10 @@ typedef struct vkrhip_device_outputs {
   const void *transmission_gpu_candidates; /* transmission_gpu_candidate_count rows (144 B): the
                                          rows of the transmissive sources once more, in source
                                          order (application.h:643-645); null when there are none */
+  const uint32_t *dirty_nodes;        /* when STAGE_DIRTY_LIST ran: the nodes the update rewrote, in
+                                         topological order (ascending index), the list
+                                         scene_mark_render_dirty builds (vkr_scene_system.c:458-479) */
+  const uint32_t *dirty_node_count;   /* ... and its length (one device word) */
 } vkrhip_device_outputs;
 
 /* Backend publication state, flattened (VkrVulkanPublishedGeometry,
@@ -330,6 +335,13 @@ int vkrhip_read_visible_rows(vkrhip_ctx *ctx, uint32_t view, uint64_t count, voi
 int vkrhip_read_commands(vkrhip_ctx *ctx, uint32_t view, uint32_t bucket, uint64_t count,
                          void *commands20);
 int vkrhip_read_world_bounds(vkrhip_ctx *ctx, uint64_t first, uint64_t count, float *out4);
+/* The render-dirty list of the last frame (STAGE_DIRTY_LIST): every node whose world
+ * matrix vkr_scene_update rewrote, in the order the reference appends them
+ * (scene_mark_render_dirty, vkr_scene_system.c:458-479, called at :1335 while the
+ * topological order is walked; the render bridge consumes the list at :2123-2124).
+ * *out_count is the length of the list (= vkrhip_frame_info::nodes_updated of a frame
+ * with STAGE_TRANSFORM); at most `capacity` entries are copied. */
+int vkrhip_read_dirty_list(vkrhip_ctx *ctx, uint64_t capacity, uint32_t *out_nodes, uint64_t *out_count);
 int vkrhip_read_candidate_prep(vkrhip_ctx *ctx, uint64_t first, uint64_t count,
                                float *sphere4, uint32_t *flags_bucket);
 

@@ -8,6 +8,8 @@ from helpers import DIRTY_WORLD, compare_frame, hip_scene_for, oracle_frame, vie
 
 pytestmark = pytest.mark.gpu
 
+STAGE_ALL, STAGE_DIRTY_LIST = 0x7, 0x100
+
 
 def _synth():
     from vulkan_renderer_amd import synth
@@ -74,6 +76,20 @@ def test_config3_sixteen_million_depth8_five_views(oracle):
         hs.mark_all(DIRTY_WORLD)
         hs.frame()
         compare_frame(hs, ref, sc, check_transform=False)
+        # a tenth of the subtrees below level 2 moves (marked on the device), with the
+        # render-dirty list: the moved set against the oracle's, frames back to back
+        lo = sc.level_offsets
+        first, count = int(lo[2]) + 7, int(lo[3] - lo[2]) // 10
+        flags = hs.read_node_flags()
+        hs.mark_nodes(first, count, DIRTY_WORLD)
+        hs.frame(STAGE_ALL | STAGE_DIRTY_LIST)
+        flags[first: first + count] |= DIRTY_WORLD
+        _, world, flags, dirty = oracle.scene_update(sc.parent, local=ref["local"], flags=flags,
+                                                     world=ref["world"])
+        got = hs.read_dirty_list()
+        assert 0 < dirty.shape[0] < sc.n and got.shape == dirty.shape and (got == dirty).all()
+        assert (hs.read_node_flags() == flags).all()
+        compare_frame(hs, ref, sc, check_transform=False)  # nothing changed place: same lists and draws
 
 
 def test_config5_sixteen_million_sixty_four_views(oracle):

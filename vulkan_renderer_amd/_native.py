@@ -27,6 +27,7 @@ STAGE_TRANSFORM, STAGE_CULL, STAGE_TRANSPARENT = 0x1, 0x2, 0x4
 STAGE_CANDIDATES, STAGE_WORLD_BOUNDS = 0x8, 0x10
 STAGE_PACK, STAGE_ENCODE = 0x20, 0x40
 STAGE_CASTER_BOUNDS = 0x80
+STAGE_DIRTY_LIST = 0x100
 STAGE_ALL = 0x7
 
 TIMER_NAMES = ["transform", "classify", "fused", "scan", "scatter", "sort", "emit",
@@ -39,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_frame", "vkrhip_get_frame_info", "vkrhip_get_device_outputs", "vkrhip_read_world",
     "vkrhip_read_locals", "vkrhip_read_node_flags", "vkrhip_read_visible",
     "vkrhip_read_transparent_visible", "vkrhip_read_transparent", "vkrhip_read_candidates",
-    "vkrhip_read_world_bounds", "vkrhip_read_candidate_prep", "vkrhip_set_publication",
+    "vkrhip_read_world_bounds", "vkrhip_read_dirty_list", "vkrhip_read_candidate_prep", "vkrhip_set_publication",
     "vkrhip_read_packed", "vkrhip_read_visible_rows", "vkrhip_read_commands", "vkrhip_set_profiling",
     "vkrhip_get_timers", "vkrhip_merge_runs", "vkrhip_concat_ranges", "vkrhip_frustum_from_matrix",
     "vkrhip_exchange_block_words", "vkrhip_exchange_result_words", "vkrhip_exchange_pack",
@@ -204,6 +205,8 @@ class DeviceOutputs(C.Structure):
         ("visible_rows", C.c_void_p),
         ("commands", C.c_void_p),
         ("transmission_gpu_candidates", C.c_void_p),
+        ("dirty_nodes", C.c_void_p),
+        ("dirty_node_count", C.c_void_p),
     ]
 
 
@@ -272,6 +275,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_comm_unique_id.argtypes = [vp]
     L.vkrhip_comm_init.argtypes = [vp, vp, u32, u32]
     L.vkrhip_comm_count.argtypes = [vp, vp]
+    L.vkrhip_read_dirty_list.argtypes = [vp, u64, vp, vp]
     L.vkrhip_mark_nodes.argtypes = [vp, u64, u64, C.c_uint8]
     L.vkrhip_debug_streams.argtypes = [vp, vp, u32]
     L.vkrhip_exchange_configure.argtypes = [vp, u32, u32, u32]

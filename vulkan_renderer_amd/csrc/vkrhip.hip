@@ -21,6 +21,7 @@
 
 #include "device_math.hpp"
 #include "k_cull.hpp"
+#include "k_dirty.hpp"
 #include "k_fused.hpp"
 #include "k_pack.hpp"
 #include "k_exchange.hpp"
@@ -182,6 +183,9 @@ struct vkrhip_ctx {
   DevBuf<uint32_t> transmission_list;  // source rows with a transmissive material, ascending
   uint64_t n_transmission = 0;
   DevBuf<uint4> transmission_rows;
+
+  // render-dirty list (allocated when the stage first runs)
+  DevBuf<uint32_t> dirty_list, dirty_block_counts, dirty_block_offsets, dirty_total;
 
   // backend pack / encode (allocated when a publication is set / the stage first runs)
   bool published = false;
@@ -824,6 +828,10 @@ void vkrhip_destroy(vkrhip_ctx *c) {
     dev_free(c->tkey2[k]);
     dev_free(c->tworld_sparse[k]);
   }
+  dev_free(c->dirty_list);
+  dev_free(c->dirty_block_counts);
+  dev_free(c->dirty_block_offsets);
+  dev_free(c->dirty_total);
   dev_free(c->pub_geometries);
   dev_free(c->pub_submeshes);
   dev_free(c->pub_materials);
@@ -1880,6 +1888,29 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
   return VKRHIP_OK;
 }
 
+// The nodes the frame's transform update rewrote, ascending (= topological order).
+static int launch_dirty_list(vkrhip_ctx *c) {
+  const uint64_t mn = c->cfg.max_nodes;
+  const uint64_t max_blocks = ceil_div(mn, DIRTY_NODES);
+  TRY(dev_alloc(c, c->dirty_list, mn));
+  TRY(dev_alloc(c, c->dirty_block_counts, max_blocks));
+  TRY(dev_alloc(c, c->dirty_block_offsets, max_blocks));
+  TRY(dev_alloc(c, c->dirty_total, 1));
+  DirtyArgs a{};
+  a.flags = c->flags();
+  a.block_counts = c->dirty_block_counts.p;
+  a.block_offsets = c->dirty_block_offsets.p;
+  a.list = c->dirty_list.p;
+  a.total = c->dirty_total.p;
+  a.n = c->n_nodes;
+  a.blocks = (uint32_t)ceil_div(c->n_nodes, DIRTY_NODES);
+  if (a.blocks) hipLaunchKernelGGL(k_dirty_count, dim3(a.blocks), dim3(DIRTY_BLOCK), 0, c->stream, a);
+  hipLaunchKernelGGL(k_dirty_scan, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, a);
+  if (a.blocks) hipLaunchKernelGGL(k_dirty_write, dim3(a.blocks), dim3(DIRTY_BLOCK), 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return VKRHIP_OK;
+}
+
 static int launch_candidates(vkrhip_ctx *c) {
   TRY(dev_alloc(c, c->cand_rows, std::max<uint64_t>(c->cfg.max_candidates, 1) * 9));
   if (!c->n_cand) return VKRHIP_OK;
@@ -1976,6 +2007,7 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
       if (stages & VKRHIP_STAGE_TRANSFORM) TRY(launch_transform(c));
       if (cull) TRY(launch_classify(c, bounds_out));
     }
+    if (stages & VKRHIP_STAGE_DIRTY_LIST) TRY(launch_dirty_list(c));
     if (c->frame_tail) {
       // the tail waits for the classify on the second stream (ev_gathered is the last
       // classify launch's own completion signal); the frame's stream goes on
@@ -2092,6 +2124,8 @@ int vkrhip_get_device_outputs(vkrhip_ctx *c, vkrhip_device_outputs *out) {
   out->packed_instances = c->packed_instances.p;
   out->visible_rows = c->visible_rows.p;
   out->commands = c->commands.p;
+  out->dirty_nodes = c->dirty_list.p;
+  out->dirty_node_count = c->dirty_total.p;
   return VKRHIP_OK;
 }
 
@@ -2276,6 +2310,17 @@ int vkrhip_read_commands(vkrhip_ctx *c, uint32_t view, uint32_t bucket, uint64_t
   return read_back(c, commands20,
                    c->commands.p + ((size_t)view * 4u + bucket) * c->cfg.partition_capacity * 5u,
                    count * 20);
+}
+
+int vkrhip_read_dirty_list(vkrhip_ctx *c, uint64_t capacity, uint32_t *out_nodes, uint64_t *out_count) {
+  if (!c || !out_count || (capacity && !out_nodes)) return VKRHIP_ERR_ARG;
+  *out_count = 0;
+  if (!c->dirty_list.p || !(c->last_stages & VKRHIP_STAGE_DIRTY_LIST))
+    return fail(c, VKRHIP_ERR_STATE, "the last frame did not run STAGE_DIRTY_LIST");
+  uint32_t total = 0;
+  TRY(read_back(c, &total, c->dirty_total.p, sizeof(total)));
+  *out_count = total;
+  return read_back(c, out_nodes, c->dirty_list.p, std::min<uint64_t>(total, capacity) * sizeof(uint32_t));
 }
 
 int vkrhip_read_world_bounds(vkrhip_ctx *c, uint64_t first, uint64_t count, float *out4) {

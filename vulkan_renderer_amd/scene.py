@@ -296,6 +296,13 @@ class HipScene:
         self._ok(self.lib.vkrhip_read_node_flags(self.ctx, first, count, N.ptr(out)))
         return out
 
+    def read_dirty_list(self) -> np.ndarray:
+        """Nodes the last frame's update rewrote, in topological order (STAGE_DIRTY_LIST)."""
+        count = C.c_uint64(0)
+        out = np.empty(self.n_nodes, np.uint32)
+        self._ok(self.lib.vkrhip_read_dirty_list(self.ctx, out.shape[0], N.ptr(out), C.byref(count)))
+        return out[: int(count.value)].copy()
+
     def read_visible(self, view: int, count: int) -> np.ndarray:
         out = np.empty(count, np.uint32)
         self._ok(self.lib.vkrhip_read_visible(self.ctx, view, count, N.ptr(out)))
