@@ -714,6 +714,33 @@ int vkrhip_gltf_read_nodes(const char *json, uint64_t length, uint32_t scene, ui
                            float *quat4, float *scale4, int32_t *mesh, uint8_t *has_matrix,
                            float *matrix16);
 
+/* The bounds of every mesh primitive of a glTF document, in file order (mesh after
+ * mesh, primitive after primitive): center / min_extents / max_extents as the
+ * reference stores them per submesh (VkrMeshAssetSubmesh,
+ * lib/src/renderer/resources/vkr_resources.h:292-294), from the "min" / "max" of the
+ * primitive's POSITION accessor (cgltf_accessor.min / .max, vendor/cgltf.h) - the
+ * values the reference's importer arrives at by a minimum / maximum over the vertex
+ * positions (vkr_mesh_loader_compute_bounds,
+ * lib/src/renderer/resources/loaders/mesh_loader.c:1159-1179; centre = (min + max) *
+ * 0.5 there and here). Host code, the JSON walker of vkrhip_gltf_read_nodes.
+ *   capacity   room in the arrays; with fewer, info is filled and
+ *              VKRHIP_ERR_CAPACITY returned (call once with 0 to size them)
+ *   mesh / primitive   index into "meshes" / into that mesh's "primitives"
+ *   material   index into "materials", -1 for none
+ *   has_bounds 1 when the POSITION accessor carries a three-component min and max
+ *   bounds12   three padded Vec3 per primitive - the layout vkrhip_set_candidates
+ *              takes: center, min_extents, max_extents; zero without bounds
+ * Any array may be NULL. VKRHIP_ERR_ARG: not JSON, or an accessor index out of range. */
+typedef struct vkrhip_gltf_meshes {
+  uint32_t mesh_count;      /* "meshes" of the document */
+  uint32_t primitive_count; /* primitives of all meshes */
+  uint32_t accessor_count;  /* "accessors" of the document */
+  uint32_t bounded_count;   /* primitives with bounds */
+} vkrhip_gltf_meshes;
+int vkrhip_gltf_read_mesh_bounds(const char *json, uint64_t length, uint32_t capacity,
+                                 vkrhip_gltf_meshes *info, uint32_t *mesh, uint32_t *primitive,
+                                 int32_t *material, uint8_t *has_bounds, float *bounds12);
+
 /* ---- scene files ---------------------------------------------------------------
  * "entities" of one of the reference's scene files (assets/scenes/ *.scene.json,
  * version 2) as per-entity arrays in file order: what scene_json_parse_parent /

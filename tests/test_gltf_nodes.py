@@ -115,20 +115,79 @@ def test_glb_container(tmp_path):
 
 
 def _scene_of(name, oracle):
-    """The scene's arrays for the frame: level-ordered TRS nodes, one row per mesh
-    node (a unit cube as its bounds: mesh data is not read), nodes given as a
-    matrix get that matrix as their local."""
+    """The scene's arrays for the frame: level-ordered TRS nodes; one row per
+    primitive of every mesh node (as the reference draws one submesh per primitive),
+    with the bounds of its POSITION accessor where the document gives them - a
+    mesh without primitives, or a primitive without accessor bounds, gets a unit
+    cube; nodes given as a matrix get that matrix as their local."""
     from vulkan_renderer_amd import gltf, synth
     gs = gltf.load_nodes(path_of(name))
+    mb = gltf.read_mesh_bounds(gltf.document_text(path_of(name)))
     n = gs.parent.shape[0]
-    rows = np.flatnonzero(gs.mesh >= 0).astype(np.uint32)
-    ident, matbits, bounds = synth.make_candidates(3, rows.astype(np.uint64))
-    bounds[:, 0:4] = 0.0
-    bounds[:, 4:7], bounds[:, 8:11] = -0.5, 0.5
+    unit = np.zeros(12, np.float32)
+    unit[4:7], unit[8:11] = -0.5, 0.5
+    rows, row_bounds = [], []
+    for node in np.flatnonzero(gs.mesh >= 0):
+        prims = np.flatnonzero(mb.mesh == gs.mesh[node])
+        for p in prims:
+            rows.append(node)
+            row_bounds.append(mb.bounds[p] if mb.has_bounds[p] else unit)
+        if prims.shape[0] == 0:
+            rows.append(node)
+            row_bounds.append(unit)
+    rows = np.asarray(rows, np.uint32)
+    ident, matbits, bounds = synth.make_candidates(3, np.arange(rows.shape[0], dtype=np.uint64))
+    if rows.shape[0]:
+        bounds[:] = np.stack(row_bounds)
     local = np.stack([oracle.local_from_trs(gs.pos[i], gs.quat[i], gs.scale[i]) for i in range(n)]) \
         if n else np.zeros((0, 16), np.float32)
     local[gs.has_matrix] = gs.matrix[gs.has_matrix]
     return gs, rows, ident, matbits, bounds, local
+
+
+def test_mesh_bounds_of_the_reference_fixture():
+    """specgloss_factor_parity.gltf (the reference's own test file): both meshes draw
+    one primitive whose POSITION accessor spans [-1,-1,0]..[1,1,0] - and that is what
+    the vertex positions in the file's embedded buffer span (the reference takes the
+    minimum and maximum over the vertices, mesh_loader.c:1159-1179)."""
+    import base64
+    import json
+    from vulkan_renderer_amd import gltf
+    text = gltf.document_text(path_of("specgloss_factor_parity.gltf"))
+    mb = gltf.read_mesh_bounds(text)
+    assert mb.mesh_count == 2 and mb.mesh.tolist() == [0, 1] and mb.primitive.tolist() == [0, 0]
+    assert mb.material.tolist() == [0, 1] and mb.has_bounds.all()
+    for p in range(2):
+        assert mb.bounds[p, 0:3].tolist() == [0.0, 0.0, 0.0]       # center
+        assert mb.bounds[p, 4:7].tolist() == [-1.0, -1.0, 0.0]     # min_extents
+        assert mb.bounds[p, 8:11].tolist() == [1.0, 1.0, 0.0]      # max_extents
+    doc = json.loads(text)
+    blob = base64.b64decode(doc["buffers"][0]["uri"].split(",", 1)[1])
+    view = doc["bufferViews"][doc["accessors"][0]["bufferView"]]
+    positions = np.frombuffer(blob, np.float32, count=4 * 3, offset=view["byteOffset"]).reshape(4, 3)
+    assert positions.min(axis=0).tolist() == mb.bounds[0, 4:7].tolist()
+    assert positions.max(axis=0).tolist() == mb.bounds[0, 8:11].tolist()
+
+
+def test_mesh_bounds_reader_cases():
+    """Meshes with two, one and no primitives; an accessor without min / max; a
+    scalar accessor's one-component min / max is not a bound; errors."""
+    from vulkan_renderer_amd import _native as N, gltf
+    mb = gltf.read_mesh_bounds(gltf.document_text(path_of("nested.gltf")))
+    assert mb.mesh_count == 3 and mb.mesh.tolist() == [0, 0, 1] and mb.primitive.tolist() == [0, 1, 0]
+    assert mb.material.tolist() == [3, -1, 0] and mb.has_bounds.tolist() == [True, True, False]
+    f = np.float32
+    assert mb.bounds[0, 4:7].tolist() == [f(-0.5), f(-1.25), f(0.125)] and mb.bounds[0, 8:11].tolist() == [f(2.5), f(0.75), f(3)]
+    assert mb.bounds[0, 0:3].tolist() == [(f(-0.5) + f(2.5)) * f(0.5), (f(-1.25) + f(0.75)) * f(0.5),
+                                          (f(0.125) + f(3)) * f(0.5)]
+    assert mb.bounds[1, 4:7].tolist() == [f(-0.1), f(-0.2), f(-0.3)] and mb.bounds[1, 8:11].tolist() == [f(0.1), f(0.2), f(0.3)]
+    assert not mb.bounds[2].any() and not mb.bounds[:, 3].any()
+    assert gltf.read_mesh_bounds(gltf.document_text(path_of("punctual_lights.gltf"))).mesh.shape[0] == 0
+    for bad in (b'{"meshes": [{"primitives": [{"attributes": {"POSITION": 4}}]}], "accessors": []}',
+                b'{"meshes": [', b'[]'):
+        with pytest.raises(N.VkrHipError) as e:
+            gltf.read_mesh_bounds(bad)
+        assert e.value.code == N.ERR_ARG
 
 
 @pytest.mark.parametrize("name", FILES)
@@ -139,7 +198,7 @@ def test_oracle_runs_the_gltf_scenes(oracle, name):
     _, world, flags, dirty = oracle.scene_update(gs.parent, local=local, flags=np.full(n, 0x02, np.uint8))
     assert dirty.shape[0] == n
     if name == "nested.gltf":
-        assert n == 7 and rows.shape[0] == 4 and gs.level_offsets.tolist() == [0, 2, 5, 6, 7]
+        assert n == 7 and rows.shape[0] == 5 and gs.level_offsets.tolist() == [0, 2, 5, 6, 7]
         # node 4 sits under 3 under 1 under 0: its world position, by hand in float64
         k = int(np.flatnonzero(gs.file_index == 4)[0])
         r = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], np.float64)   # 90 degrees about +Y

@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "vkrhip_shadow_system_invalidate_fit_history", "vkrhip_shadow_system_update",
     "vkrhip_shadow_fit_cascade", "vkrhip_shadow_fit_relevant_caster_z",
     "vkrhip_shadow_quantize_extent_up", "vkrhip_shadow_apply_fit_hysteresis",
-    "vkrhip_shadow_build_view_set", "vkrhip_get_caster_bounds", "vkrhip_gltf_read_nodes",
+    "vkrhip_shadow_build_view_set", "vkrhip_get_caster_bounds", "vkrhip_gltf_read_nodes", "vkrhip_gltf_read_mesh_bounds",
     "vkrhip_host_alloc", "vkrhip_host_free", "vkrhip_scene_read_entities",
 ]
 
@@ -125,6 +125,11 @@ class ShadowSystem(C.Structure):  # vkrhip_shadow_system
 class GltfNodes(C.Structure):  # vkrhip_gltf_nodes
     _fields_ = [("node_count", C.c_uint32), ("scene_count", C.c_uint32), ("scene", C.c_uint32),
                 ("scene_nodes", C.c_uint32)]
+
+
+class GltfMeshes(C.Structure):  # vkrhip_gltf_meshes
+    _fields_ = [("mesh_count", C.c_uint32), ("primitive_count", C.c_uint32), ("accessor_count", C.c_uint32),
+                ("bounded_count", C.c_uint32)]
 
 
 class SceneEntities(C.Structure):
@@ -312,6 +317,7 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     L.vkrhip_shadow_build_view_set.argtypes = [C.POINTER(ShadowSystem), vp, vp, vp, vp, vp]
     L.vkrhip_get_caster_bounds.argtypes = [vp, vp, vp]
     L.vkrhip_gltf_read_nodes.argtypes = [C.c_char_p, u64, u32, u32, C.POINTER(GltfNodes)] + [vp] * 8
+    L.vkrhip_gltf_read_mesh_bounds.argtypes = [C.c_char_p, u64, u32, C.POINTER(GltfMeshes)] + [vp] * 5
     L.vkrhip_static_init.argtypes = [C.c_int]
     L.vkrhip_exchange_merge_static.argtypes = [C.c_int, u32, vp, u32, u32, u32, vp, vp, vp, vp]
     L.vkrhip_frustum_from_matrix.argtypes = [vp, vp]

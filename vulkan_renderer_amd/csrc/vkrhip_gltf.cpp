@@ -353,6 +353,121 @@ int vkrhip_gltf_read_nodes(const char *json, uint64_t length, uint32_t scene, ui
   return VKRHIP_ERR_ARG;  // out of host memory while parsing
 }
 
+// The bounds of every mesh primitive, from the POSITION accessor's "min" / "max"
+// (glTF 2.0 requires both on POSITION accessors): what the reference computes over
+// the primitive's vertex positions when it imports the file
+// (vkr_mesh_loader_compute_bounds, mesh_loader.c:1159-1179: component-wise minimum
+// and maximum, centre = (min + max) * 0.5) and stores as the submesh's center /
+// min_extents / max_extents (vkr_resources.h:292-294).
+int vkrhip_gltf_read_mesh_bounds(const char *json, uint64_t length, uint32_t capacity,
+                                 vkrhip_gltf_meshes *info, uint32_t *mesh, uint32_t *primitive,
+                                 int32_t *material, uint8_t *has_bounds, float *bounds12) try {
+  if (!json || !info) return VKRHIP_ERR_ARG;
+  std::memset(info, 0, sizeof(*info));
+  struct Primitive {
+    uint32_t mesh, index;
+    int64_t position = -1;
+    int32_t material = -1;
+  };
+  struct Accessor {
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+    bool have_lo = false, have_hi = false;
+  };
+  std::vector<Primitive> prims;
+  std::vector<Accessor> accessors;
+  uint32_t mesh_count = 0;
+  Cursor c{json, json + length};
+  const bool parsed = parse_object(c, 0, [&](const std::string &key, Cursor &v) {
+    if (key == "meshes") {
+      prims.clear();
+      mesh_count = 0;
+      return parse_array(v, 1, [&](uint32_t m, Cursor &mv) {
+        mesh_count = m + 1u;
+        return parse_object(mv, 2, [&](const std::string &k, Cursor &pv) {
+          if (k != "primitives") return skip_value(pv, 3);
+          return parse_array(pv, 3, [&](uint32_t pi, Cursor &ev) {
+            prims.emplace_back();
+            prims.back().mesh = m;
+            prims.back().index = pi;
+            const size_t at = prims.size() - 1;
+            return parse_object(ev, 4, [&](const std::string &pk, Cursor &av) {
+              if (pk == "material") {
+                uint32_t id;
+                if (!parse_index(av, &id) || id > 0x7fffffffu) return false;
+                prims[at].material = (int32_t)id;
+                return true;
+              }
+              if (pk != "attributes") return skip_value(av, 5);
+              return parse_object(av, 5, [&](const std::string &ak, Cursor &iv) {
+                if (ak != "POSITION") return skip_value(iv, 6);
+                uint32_t id;
+                if (!parse_index(iv, &id)) return false;
+                prims[at].position = id;
+                return true;
+              });
+            });
+          });
+        });
+      });
+    }
+    if (key == "accessors") {
+      accessors.clear();
+      return parse_array(v, 1, [&](uint32_t, Cursor &av) {
+        accessors.emplace_back();
+        const size_t at = accessors.size() - 1;
+        return parse_object(av, 2, [&](const std::string &k, Cursor &mv) {
+          // (only three-component bounds are of interest; others are skipped whole)
+          if (k == "min" || k == "max") {
+            Cursor probe = mv;
+            float three[3];
+            if (parse_floats(probe, 3, three, 3)) {
+              Accessor &a = accessors[at];
+              std::memcpy(k == "min" ? a.lo : a.hi, three, sizeof(three));
+              (k == "min" ? a.have_lo : a.have_hi) = true;
+              mv = probe;
+              return true;
+            }
+          }
+          return skip_value(mv, 3);
+        });
+      });
+    }
+    return skip_value(v, 1);
+  });
+  skip_space(c);
+  if (!parsed || c.p != c.end) return VKRHIP_ERR_ARG;  // not a JSON document
+  for (const Primitive &p : prims)
+    if (p.position >= 0 && (uint64_t)p.position >= accessors.size()) return VKRHIP_ERR_ARG;
+  info->mesh_count = mesh_count;
+  info->primitive_count = (uint32_t)prims.size();
+  info->accessor_count = (uint32_t)accessors.size();
+  if (prims.size() > capacity) return VKRHIP_ERR_CAPACITY;  // info tells how much room the arrays need
+  for (size_t i = 0; i < prims.size(); ++i) {
+    const Primitive &p = prims[i];
+    if (mesh) mesh[i] = p.mesh;
+    if (primitive) primitive[i] = p.index;
+    if (material) material[i] = p.material;
+    const Accessor *a = p.position >= 0 ? &accessors[(size_t)p.position] : nullptr;
+    const bool have = a && a->have_lo && a->have_hi;
+    if (has_bounds) has_bounds[i] = have ? 1 : 0;
+    if (have) info->bounded_count += 1u;
+    if (bounds12) {
+      float *o = bounds12 + 12 * i;
+      std::memset(o, 0, 12 * sizeof(float));
+      if (have)
+        for (int k = 0; k < 3; ++k) {
+          o[k] = (a->lo[k] + a->hi[k]) * 0.5f;  // center
+          o[4 + k] = a->lo[k];                   // min_extents
+          o[8 + k] = a->hi[k];                   // max_extents
+        }
+    }
+  }
+  return VKRHIP_OK;
+} catch (...) {
+  return VKRHIP_ERR_ARG;  // out of host memory while parsing
+}
+
+
 // "entities" of one of the reference's scene files (version 2).
 int vkrhip_scene_read_entities(const char *json, uint64_t length, uint32_t capacity,
                                vkrhip_scene_entities *info, uint32_t *parent, float *pos4, float *quat4,

@@ -68,6 +68,37 @@ def read_nodes(text: bytes, scene: int | None = None) -> GltfNodes:
 
 
 @dataclass
+class GltfMeshBounds:
+    """Per-primitive arrays in FILE order (mesh after mesh, primitive after primitive)."""
+    mesh: np.ndarray        # (p,) u32 index into "meshes"
+    primitive: np.ndarray   # (p,) u32 index into that mesh's primitives
+    material: np.ndarray    # (p,) i32, -1 = none
+    has_bounds: np.ndarray  # (p,) bool: the POSITION accessor carries min and max
+    bounds: np.ndarray      # (p,12) f32: center, min_extents, max_extents as padded Vec3
+    mesh_count: int
+
+
+def read_mesh_bounds(text: bytes) -> GltfMeshBounds:
+    """vkrhip_gltf_read_mesh_bounds: the submesh bounds the reference derives from a
+    primitive's vertex positions, taken from the POSITION accessor's min / max."""
+    lib = N.load()
+    info = N.GltfMeshes()
+    rc = lib.vkrhip_gltf_read_mesh_bounds(text, len(text), 0, C.byref(info), *([None] * 5))
+    if rc not in (N.OK, N.ERR_CAPACITY):
+        raise N.VkrHipError(rc, "vkrhip_gltf_read_mesh_bounds: not a glTF document this reader accepts")
+    p = info.primitive_count
+    mesh, primitive = np.zeros(p, np.uint32), np.zeros(p, np.uint32)
+    material = np.zeros(p, np.int32)
+    has_bounds = np.zeros(p, np.uint8)
+    bounds = np.zeros((p, 12), np.float32)
+    rc = lib.vkrhip_gltf_read_mesh_bounds(text, len(text), p, C.byref(info), N.ptr(mesh), N.ptr(primitive),
+                                          N.ptr(material), N.ptr(has_bounds), N.ptr(bounds))
+    if rc != N.OK:
+        raise N.VkrHipError(rc, "vkrhip_gltf_read_mesh_bounds")
+    return GltfMeshBounds(mesh, primitive, material, has_bounds.astype(bool), bounds, int(info.mesh_count))
+
+
+@dataclass
 class GltfScene:
     """The chosen scene's nodes, level-ordered for vkrhip_set_hierarchy."""
     file_index: np.ndarray     # (m,) glTF node index of every scene node, in level order
