@@ -1282,6 +1282,165 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
   }
 }
 
+constexpr uint32_t GATHER_MANY_VIEWS = 8;
+
+// k_gather for many views (more than GATHER_MANY_VIEWS): four views per step. Lane
+// 16 j + s stands for slot s of the step's view j, and per state bucket a scan
+// inside the 16-lane rows gives every (view, bucket, slot) its position behind the
+// segment's scanned offset, for four views at the price of one. Few survivors are
+// then written pair by pair, each lane walking the set bits of its own four bucket
+// masks one after the other; a view with many goes slot by slot as in k_gather.
+// With 64 views over 16M rows the launch takes 205 us where k_gather takes 289 us;
+// with one or five views it loses (a view's 64 pairs on 64 lanes walk their bits in
+// fewer steps than on 16 lanes: 16M-node hierarchy, five views, frame 565 -> 572
+// us), hence two kernels.
+__global__ __launch_bounds__(GATHER_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_gather_many(GatherArgs a) {
+  static_assert(CULL_SLOTS == 16, "lane layouts below");
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = t >> 6;
+  const uint32_t vrows = a.views * 4u;
+  if (blockIdx.x == 0)
+    for (uint32_t v = t; v < a.views; v += GATHER_BLOCK)
+      a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity, a.visible_stride);
+
+  const uint64_t seg = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
+  if (seg >= a.segments) return;  // wave-uniform; no block-wide barrier below
+  const unsigned long long *record = a.seg_masks + seg * seg_record_words(a.views);
+  // (the same address, known to be the same for the whole wave: scalar loads)
+  const unsigned long long *uniform_record =
+      a.seg_masks + (((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seg >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seg)) *
+                        seg_record_words(a.views);
+  const uint32_t slot = lane & 15u, bucket = lane >> 4;
+
+  // What the wave needs for four views, requested in one go: lane -> (view v0 +
+  // lane / 16, slot lane % 16) for the masks; lane j < 16 -> row 4 v0 + j for the
+  // row's scanned offset and the four bucket totals of the row's view.
+  struct Chunk {
+    unsigned long long masks;
+    uint32_t row, offset, total[4];
+  };
+  auto request = [&](uint32_t v0) {
+    Chunk c;
+    c.masks = record[min(v0 + bucket, a.views - 1u) * CULL_SLOTS + slot];
+    c.row = min(v0 * 4u + (lane & 15u), vrows - 1u);
+    c.offset = a.seg_offsets[(uint64_t)c.row * a.seg_stride + seg];
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) c.total[b] = a.row_totals[(c.row & ~3u) + b];
+    return c;
+  };
+  Chunk cur = request(0u);
+  const uint32_t origin = a.seg_first[seg];
+  // the four state-bucket masks of this lane's slot (lanes 16 j + s all hold slot s)
+  const unsigned long long *slot_in_bucket = record + CULL_SLOTS * a.views + slot * 4u;
+  const unsigned long long inb0 = slot_in_bucket[0], inb1 = slot_in_bucket[1];
+  const unsigned long long inb2 = slot_in_bucket[2], inb3 = slot_in_bucket[3];
+  // (a set bit always stands for a candidate; the clamp keeps the loads inside the
+  // arrays whatever a record holds)
+  const uint32_t last_candidate = (uint32_t)(a.candidates - 1u);
+  auto source_row = [&](uint32_t candidate) -> uint32_t {
+    return a.remap ? a.remap[min(candidate, last_candidate)] : (uint32_t)(a.index_base + candidate);
+  };
+
+  gather_blend_rows<1>(a, lane < (uint32_t)CULL_SLOTS ? record[CULL_SLOTS * (a.views + 4u) + lane] : 0ull,
+                       [&](uint32_t) { return origin; },
+                       [&](uint32_t) { return a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg]; });
+
+  for (uint32_t v0 = 0; v0 < a.views; v0 += 4u) {
+    const Chunk c = cur;
+    if (v0 + 4u < a.views) cur = request(v0 + 4u);  // in flight while this chunk is written
+    // where the row's bucket starts inside its view's list and how much of it is
+    // kept (as prefix_state lays the buckets out)
+    uint32_t row_start = 0u, row_kept = 0u;
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) {
+      const uint32_t room = bucket_room(c.total[b], a.partition_capacity, a.visible_stride, row_start);
+      if (b == (c.row & 3u)) row_kept = room;
+      if (b < (c.row & 3u)) row_start += room;
+    }
+
+    // Four views at a time: lane 16 j + s stands for (view v0 + j, slot s). Per state
+    // bucket the slots' survivor counts are scanned inside the 16-lane row (four
+    // shifted adds), which places every (bucket, slot) pair of all four views at once;
+    // a view with few survivors (the usual case) is then written pair by pair, each
+    // lane walking the set bits of its own masks, bucket after bucket.
+    const uint32_t j = bucket;  // the lane's view inside the chunk
+    const unsigned long long mine = v0 + j < a.views ? c.masks : 0ull;
+    const unsigned long long mb[4] = {mine & inb0, mine & inb1, mine & inb2, mine & inb3};
+    uint32_t excl[4], view_total = 0u;
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) {
+      const uint32_t count = (uint32_t)__popcll(mb[b]);
+      uint32_t incl = count;
+      incl += dpp_or_zero<0x111, 0xf>(incl);  // row_shr:1
+      incl += dpp_or_zero<0x112, 0xf>(incl);  // row_shr:2
+      incl += dpp_or_zero<0x114, 0xf>(incl);  // row_shr:4
+      incl += dpp_or_zero<0x118, 0xf>(incl);  // row_shr:8
+      excl[b] = incl - count;
+      view_total += (uint32_t)__shfl((int)incl, (int)(lane | 15u), 64);
+    }
+    const bool dense = view_total > GATHER_SPARSE_LIMIT;  // the same for the 16 lanes of a view
+    const unsigned long long dense_lanes = __ballot(dense);
+    {
+      uint32_t *list = a.visible + (uint64_t)(v0 + j) * a.visible_stride;
+#pragma unroll
+      for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t row_lane = j * 4u + b;
+        // position inside the bucket (before the clamp), start of the bucket, entries kept
+        uint32_t p = (uint32_t)__shfl((int)c.offset, (int)row_lane, 64) + excl[b];
+        const uint32_t start = (uint32_t)__shfl((int)row_start, (int)row_lane, 64);
+        const uint32_t kept = (uint32_t)__shfl((int)row_kept, (int)row_lane, 64);
+        unsigned long long left = dense ? 0ull : mb[b];
+        while (__ballot(left != 0ull) != 0ull) {
+          if (left != 0ull) {
+            const uint32_t bit = (uint32_t)__ffsll((long long)left) - 1u;
+            left &= left - 1ull;
+            if (p < kept) list[start + p] = source_row(origin + slot * 64u + bit);
+            ++p;
+          }
+        }
+      }
+    }
+
+    // views with many survivors: one lane per candidate, slot by slot; the slot's
+    // masks are the same for the whole wave (scalar values), so a lane's place among
+    // its bucket's survivors is a masked bit count, 64 consecutive entries per store
+    for (uint32_t jd = 0; jd < 4u; ++jd) {  // wave-uniform
+      if (!((dense_lanes >> (16u * jd)) & 1ull)) continue;
+      uint32_t *list = a.visible + (uint64_t)(v0 + jd) * a.visible_stride;
+      uint32_t base[4], limit[4];
+#pragma unroll
+      for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t row_lane = jd * 4u + b;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)row_start, (int)row_lane);
+        base[b] = first + (uint32_t)__builtin_amdgcn_readlane((int)c.offset, (int)row_lane);
+        limit[b] = first + (uint32_t)__builtin_amdgcn_readlane((int)row_kept, (int)row_lane);
+      }
+      // (constant address space: nothing in this kernel writes the records)
+      const uniform_ptr<unsigned long long> slot_buckets = as_uniform(uniform_record + CULL_SLOTS * a.views);
+#pragma unroll 2
+      for (uint32_t k = 0; k < (uint32_t)CULL_SLOTS; ++k) {
+        const unsigned long long m = readlane64(c.masks, jd * 16u + k);
+        if (m == 0ull) continue;  // wave-uniform
+        uint32_t pos = 0u, end = 0u;
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {
+          const unsigned long long mbk = m & slot_buckets[k * 4u + b];
+          const uint32_t below = __builtin_amdgcn_mbcnt_hi(
+              (uint32_t)(mbk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mbk, 0u));
+          if ((mbk >> lane) & 1ull) {
+            pos = base[b] + below;
+            end = limit[b];
+          }
+          base[b] += (uint32_t)__popcll(mbk);
+        }
+        if (pos < end) list[pos] = source_row(origin + k * 64u + lane);
+      }
+    }
+  }
+}
+
 // What k_place knows about one (segment, view): the entry indices at which the
 // stretch's buckets end, and per bucket the distance from an entry's index to its
 // place in the view's list and the end of what the list keeps of the bucket.

@@ -1740,7 +1740,8 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
     g.partition_capacity = c->cfg.partition_capacity;
     // (a wave of k_gather takes one segment, a wave of k_place PLACE_SEGS)
     const unsigned grid = (unsigned)ceil_div(segments, (GATHER_BLOCK / 64) * (c->frame_staged ? PLACE_SEGS : 1u));
-    hipLaunchKernelGGL(c->frame_staged ? k_place : k_gather, dim3(grid), dim3(GATHER_BLOCK), 0, on, g);
+    hipLaunchKernelGGL(c->frame_staged ? k_place : (c->views > GATHER_MANY_VIEWS ? k_gather_many : k_gather),
+                       dim3(grid), dim3(GATHER_BLOCK), 0, on, g);
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
