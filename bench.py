@@ -90,7 +90,7 @@ KERNEL_NAMES = {"transform": "k_propagate_classify", "classify": "k_classify",
 VALU_PEAK_INSTS_PER_S = 256 * 4 * 2.4e9 / 4
 
 
-def pmc_valu_insts(workload_name: str, overridden: bool, kernel: str):
+def pmc_valu_insts(workload_name: str, overridden: bool, kernel: str, variant=None):
     """SQ_INSTS_VALU per step of the dominant kernel from the committed counter pass
     of this workload (wave instructions, summed over the kernel's dispatches of one
     frame), or None."""
@@ -104,7 +104,9 @@ def pmc_valu_insts(workload_name: str, overridden: bool, kernel: str):
         data = json.load(fh)
     total = 0.0
     for name, k in data["kernels"].items():
-        if name.startswith(kernel) and "valu_insts_per_dispatch" in k:
+        targs = [x.strip() for x in name[name.find("<") + 1: name.rfind(">")].split(",")] if "<" in name else []
+        if (name.startswith(kernel) and "valu_insts_per_dispatch" in k
+                and (variant is None or (len(targs) > 3 and targs[3] == variant))):
             total += k["dispatches_per_frame"] * k["valu_insts_per_dispatch"]
     return (total or None), os.path.relpath(paths[-1], ROOT)
 
@@ -271,7 +273,8 @@ def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden)
     # the same kernel against the vector-instruction roof (wave instructions per step
     # from the committed counter pass over the kernel's live duration): whichever
     # fraction is higher names the bound
-    insts, insts_source = pmc_valu_insts(setup.name, overridden, KERNEL_NAMES[dominant])
+    insts, insts_source = pmc_valu_insts(setup.name, overridden, KERNEL_NAMES[dominant],
+                                         {"fused": "true", "transform": "false"}.get(dominant))
     if insts and dom_avg_s > 0:
         valu_frac = insts / dom_avg_s / VALU_PEAK_INSTS_PER_S
         roofline["roofline_valu"] = {
