@@ -958,15 +958,19 @@ __device__ __forceinline__ uint4 load_counts4(const uint4 *row, uint64_t q, uint
 // totals, and sweep 2 re-reads the run (from cache), scans it 64 uint4 at a time
 // with wave shuffles and writes the exclusive prefix: two memory round trips for
 // any segment count.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
-  __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+// THREADS: 1024, or 256 for short rows - a block of four waves of this kernel's 46
+// registers finds room beside the next frame's classify blocks on every SIMD, a
+// block of sixteen does not (see tail_on_second_stream in vkrhip.hip).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_scan(ScanArgs a) {
+  __shared__ uint32_t s_wave[THREADS / 64];
   const uint32_t r = blockIdx.x;
   const uint4 *row = reinterpret_cast<const uint4 *>(a.seg_counts + (uint64_t)r * a.seg_stride);
   uint4 *out = reinterpret_cast<uint4 *>(a.seg_offsets + (uint64_t)r * a.seg_stride);
   const uint64_t quads = (a.segments + 3u) / 4u;
   const uint32_t w = threadIdx.x >> 6;
   const uint32_t lane = lane_id();
-  const uint64_t wave_quads = ((quads + SCAN_BLOCK / 64 - 1) / (SCAN_BLOCK / 64) + 63u) & ~(uint64_t)63u;
+  const uint64_t wave_quads = ((quads + THREADS / 64 - 1) / (THREADS / 64) + 63u) & ~(uint64_t)63u;
   const uint64_t qb = min((uint64_t)w * wave_quads, quads);
   const uint64_t qe = min(qb + wave_quads, quads);
 
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
   if (lane == 0) s_wave[w] = wave_total;
   __syncthreads();
   uint32_t carry = 0u, total = 0u;
-  for (uint32_t k = 0; k < SCAN_BLOCK / 64; ++k) {
+  for (uint32_t k = 0; k < THREADS / 64; ++k) {
     const uint32_t x = s_wave[k];
     if (k < w) carry += x;
     total += x;
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(ScanArgs a) {
     carry += (uint32_t)__shfl((int)incl, 63, 64);
   }
   if (r == 0 && a.clear != nullptr)
-    for (uint32_t k = threadIdx.x; k < a.clear_words; k += SCAN_BLOCK) a.clear[k] = 0u;
+    for (uint32_t k = threadIdx.x; k < a.clear_words; k += THREADS) a.clear[k] = 0u;
   if (threadIdx.x == 0) {
     a.row_totals[r] = total;
     if (r == a.views * 4u) {  // the transparent row

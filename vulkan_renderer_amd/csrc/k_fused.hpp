@@ -332,12 +332,19 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
 // parent window and no matrix product to hold and fits five waves, which pays
 // when many views make the classification the longer part of a round; without
 // the cull phase it needs 71 registers and fits six (8M roots: 197 -> 193 us).
-constexpr int fused_waves(bool has_parent, bool cull) { return has_parent ? 4 : (cull ? 5 : 6); }
+// ROOM: the root-level cull variant at four waves as well. A frame whose tail runs
+// beside the NEXT frame's launch needs that launch to leave room on every SIMD for a
+// wave of the tail's kernels (up to 124 registers): five waves of 91 registers
+// leave 57, four leave 148.
+constexpr int fused_waves(bool has_parent, bool cull, bool room = false) {
+  return has_parent ? 4 : (cull ? (room ? 4 : 5) : 6);
+}
 // STAGED: the block expands its segment's survivors itself (segment_finish_staged).
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
-          bool STREAM = false, bool STAGED = false>
+          bool STREAM = false, bool STAGED = false, bool ROOM = false>
 __global__ __launch_bounds__(FUSED_BLOCK)
-    __attribute__((amdgpu_waves_per_eu(fused_waves(HAS_PARENT, CULL), fused_waves(HAS_PARENT, CULL)))) void
+    __attribute__((amdgpu_waves_per_eu(fused_waves(HAS_PARENT, CULL, ROOM),
+                                       fused_waves(HAS_PARENT, CULL, ROOM)))) void
 k_propagate_classify(FusedArgs a) {
   __shared__ float4 s_mat[FUSED_BLOCK * MAT_LDS_STRIDE];  // wave w uses slots [64 w, 64 w + 64)
   __shared__ float4 s_par[HAS_PARENT && !TOP ? FUSED_BLOCK : 1];  // wave w: its parent window, 64 columns

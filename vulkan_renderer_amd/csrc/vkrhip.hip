@@ -1528,9 +1528,20 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
   const dim3 g(grid), b(FUSED_BLOCK);
   const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c)
                          : cull_shared_bytes(a.c.views);
+  // (root level of a frame whose tail runs beside the next frame: see fused_waves)
+  constexpr bool kRootLevel = !HAS_PARENT && !TOP;
   if (c->frame_staged) {  // (never with tie counting or world bounds)
+    if (kRootLevel && c->frame_tail)
+      launch_timed(c, VKRHIP_TIMER_FUSED, first,
+                   k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, true, kRootLevel>, g, b, lds, a);
+    else
+      launch_timed(c, VKRHIP_TIMER_FUSED, first,
+                   k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, true>, g, b, lds, a);
+    return;
+  }
+  if (kRootLevel && c->frame_tail && !ties && !bounds_out) {
     launch_timed(c, VKRHIP_TIMER_FUSED, first,
-                 k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, true>, g, b, lds, a);
+                 k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, kRootLevel>, g, b, lds, a);
     return;
   }
   if (ties) {
@@ -1709,7 +1720,10 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
     s.host_hint = c->host_hint;
     s.clear = reinterpret_cast<uint32_t *>(c->counter_block(next_block));
     s.clear_words = (uint32_t)(vkrhip_ctx::kBlockBytes / sizeof(uint32_t));
-    hipLaunchKernelGGL(k_scan, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, on, s);
+    if (segments <= 4096u)
+      hipLaunchKernelGGL(k_scan<256>, dim3(c->views * 4u + 1u), dim3(256), 0, on, s);
+    else
+      hipLaunchKernelGGL(k_scan<SCAN_BLOCK>, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, on, s);
     HIP_TRY(c, hipGetLastError());
     c->block_clean[next_block] = true;
   }
