@@ -16,7 +16,7 @@ def main():
         torch.cuda.set_device(0)
         torch.zeros(1, device="cuda")
         from vulkan_renderer_amd import HipScene, build_view_set, synth
-        n = 4096
+        n = int(os.environ.get("HOST_COST_NODES", "4096"))
         sc = synth.flat_scene(n, seed=1)
         vs = synth.camera_views(cascades=0)
         planes, required = build_view_set(vs.view, vs.projection, vs.light_view_proj)
@@ -35,7 +35,19 @@ def main():
                 spent += time.perf_counter() - t0
                 if k % 8 == 7:
                     hs.sync()
-            print(sys.argv[1], {"frame_host_us": round(spent / reps * 1e6, 1)})
+            # ... and the frame period when nothing but the device paces the loop
+            hs.sync()
+            t0 = time.perf_counter()
+            inside = 0.0
+            for k in range(reps):
+                t1 = time.perf_counter()
+                hs.mark_all(2); hs.frame()
+                inside += time.perf_counter() - t1
+            hs.sync()
+            period = (time.perf_counter() - t0) / reps
+            print(sys.argv[1], {"nodes": n, "frame_host_us": round(spent / reps * 1e6, 1),
+                                "period_us": round(period * 1e6, 1),
+                                "host_us_inside_calls_unsynced": round(inside / reps * 1e6, 1)})
         return
     for tail in ("0", "2"):
         env = dict(os.environ, VKRHIP_OVERLAP_TAIL=tail, VKRHIP_OVERLAP_SORT=tail)
