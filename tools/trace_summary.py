@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Summarises a rocprofv3 --kernel-trace CSV: per-kernel statistics and the
+"""Summarises a rocprofv3 --kernel-trace CSV: per-kernel statistics, the
 timeline (start offset, duration, gap to the previous kernel) of the last
 complete frame, a frame being the kernels from one k_propagate_* / k_classify
-launch sequence to the next."""
+launch sequence to the next, and the last kernels of the run with their queues
+(kernels of two streams overlap there)."""
 import csv
 import glob
 import os
@@ -23,8 +24,12 @@ def main() -> int:
     for path in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
         with open(path, newline="") as fh:
             for r in csv.DictReader(fh):
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]),
+                             r.get("Queue_Id", "0")))
     rows.sort()
+    queues = {q: i + 1 for i, q in enumerate(sorted({r[3] for r in rows}))}
+    timeline = rows[-int(os.environ.get("TIMELINE_KERNELS", "48")):]
+    rows = [r[:3] for r in rows]
     stats = defaultdict(list)
     for s, e, k in rows:
         stats[k].append((e - s) / 1e3)
@@ -46,6 +51,11 @@ def main() -> int:
             print(f"  {(s - t0)/1e3:9.2f}  dur {(e - s)/1e3:8.2f}  gap {gap:6.2f}  {k}")
             prev_end = e
         print(f"  frame period {(rows[b][0] - t0)/1e3:.2f} us")
+    if timeline:
+        t0 = timeline[0][0]
+        print("\ntimeline of the last kernels (start, end, duration in us, queue, kernel):")
+        for s, e, k, q in timeline:
+            print(f"  {(s - t0)/1e3:9.1f} {(e - t0)/1e3:9.1f} {(e - s)/1e3:8.1f} q{queues[q]} {k[:60]}")
     return 0
 
 
