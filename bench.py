@@ -236,14 +236,14 @@ def measure(setup, steps, warmup, dirty, submeshes, exchange, fence, overridden,
     # and the rate is back after about twenty (tools/clock_ramp_probe.py; 30 ms of
     # unrelated device work ahead of the frames does not change that). A renderer
     # runs frame after frame, so the steady rate is the one to report.
-    probe = 3
+    probe = 3 if (SETTLE_SECONDS > 0 or min_seconds > 0) else 0
     t0 = time.perf_counter()
     for _ in range(probe):
         step()
         if exchange is not None:
             exchange.finish()
     fence()
-    frame_s = max((time.perf_counter() - t0) / probe, 1e-6)
+    frame_s = max((time.perf_counter() - t0) / max(probe, 1), 1e-6)
     if min_seconds > 0:
         steps = max(steps, int(min_seconds / frame_s))
     setup.timed_steps = steps

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Hardware-counter passes over one bench.py configuration, one rocprofv3 run per
 # counter group (the SQ and TCC blocks cannot hold more in a single run). Each pass
-# runs 1 warm-up + 3 timed frames = 4 frames of the full path.
+# runs 1 warm-up + 3 timed frames = 4 frames of the full path (no settling frames:
+# the summary divides the dispatch counts by that number).
 #   tools/pmc_passes.sh <out-dir> <bench.py arguments...>
 set -e
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
+export VKR_BENCH_SETTLE_S=0
 run_pass() {
   name=$1; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" -d "$ROOT/$OUT/$name" --output-format csv -- \
