@@ -1061,7 +1061,8 @@ struct GatherArgs {
   CompactionState *states;  // written by block 0
   uint32_t *visible;        // [view][visible_stride]
   uint64_t *keys;           // compact sort keys of the visible blend rows: depth bits << 32 | place
-  uint32_t *tsrc;           // the candidate of every visible blend row, by place
+  uint32_t *tsrc;           // the candidate of every visible blend row, by place; null: the
+                            //   compact key carries the candidate itself instead of the place
   const float4 *world;      // with tworld: the rows' world matrices are set aside by place
   const uint32_t *node;     //   (candidate -> node, null = identity)
   float4 *tworld;           // null: the emission reads world[] in place
@@ -1148,8 +1149,13 @@ __device__ __forceinline__ void gather_blend_rows(const GatherArgs &a, unsigned 
         a.tworld[pos * 4u + 2u] = c2;
         a.tworld[pos * 4u + 3u] = c3;
       }
-      a.keys[pos] = (key & 0xffffffff00000000ull) | pos;
-      a.tsrc[pos] = candidate;
+      // (either low word ascends with the candidate, which is all the sort asks of it)
+      if (a.tsrc) {
+        a.keys[pos] = (key & 0xffffffff00000000ull) | pos;
+        a.tsrc[pos] = candidate;
+      } else {
+        a.keys[pos] = (key & 0xffffffff00000000ull) | candidate;
+      }
     }
   }
 }

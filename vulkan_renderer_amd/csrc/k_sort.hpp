@@ -454,7 +454,7 @@ struct EmitArgs {
   const uint64_t *keys;      // sorted compact keys: ascending, or descending when keys_descending
   const uint32_t *counters;  // CNT_TRANSPARENT
   const float4 *tworld;      // 4 x float4 per visible blend row
-  const uint32_t *tsrc;      // its candidate
+  const uint32_t *tsrc;      // its candidate; null: the key's low word IS the candidate
   const float4 *world;       // when tworld is null (single stream): the matrices are read in place,
   const uint32_t *node;      //   through candidate -> node (null = identity)
   const uint4 *ident;  // 2 x uint4 per candidate
@@ -478,36 +478,44 @@ __host__ __device__ __forceinline__ uint32_t encode_scene_object_id(uint32_t ren
 // Output rows of vkr_transparent_draw_emit (lib/src/renderer/vkr_visibility.c:15-35)
 // are written as 16-byte pieces: pieces 0-2 are the VkrDrawItem, 3-7 the
 // VkrInstanceDataGPU; eight lanes take one row so that each output array is
-// written in consecutive 16-byte pieces. Split in two so that a caller can
-// request the gathered inputs before it knows the output row.
+// written in consecutive 16-byte pieces. Every piece is made from ONE 16-byte load
+// whose address is computed, not branched to (the identity words of the row's
+// candidate, or a column of its world matrix), so a caller can request the pieces
+// of several rows back to back and before it knows the output rows.
 //
-// The part of piece `piece` that does not depend on the output row.
-__device__ __forceinline__ uint4 emit_piece_gather(const EmitArgs &a, uint64_t key,
-                                                   uint32_t piece) {
-  const uint32_t p = (uint32_t)key;  // the row's place among the visible blend rows
-  if (piece >= 3u && piece < 7u) {
-    float4 c;
-    if (a.tworld) {
-      c = a.tworld[(uint64_t)p * 4u + (piece - 3u)];
-    } else {
-      const uint32_t i = a.tsrc[p];
-      const uint64_t nd = a.node ? a.node[i] : i;
-      c = a.world[nd * 4u + (piece - 3u)];
-    }
-    return make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z),
-                      __float_as_uint(c.w));
-  }
-  const uint32_t i = a.tsrc[p];
-  if (piece == 0u) return a.ident[(uint64_t)i * 2u];  // mesh.id/.generation, geometry.id/.generation
-  if (piece == 1u) {
-    const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
-    return make_uint4(id1.x, id1.y, id1.z, 1u);  // submesh_index, material, instance_count
-  }
+// The candidate of the row with this key: the low word of a compact key is the
+// row's place, under which the gather left the candidate (tsrc), or - when the
+// rows' matrices were set aside under the candidate index - the candidate itself.
+__device__ __forceinline__ uint32_t emit_candidate(const EmitArgs &a, uint64_t key) {
+  const uint32_t p = (uint32_t)key;
+  return a.tsrc ? a.tsrc[p] : p;
+}
+
+// Where the 16 bytes come from that piece `piece` of candidate i's row is made of.
+__device__ __forceinline__ const uint4 *emit_piece_source(const EmitArgs &a, uint64_t key, uint32_t i,
+                                                          uint64_t nd, uint32_t piece) {
+  const bool column = piece >= 3u && piece < 7u;
+  const float4 *matrix = a.tworld ? a.tworld + (uint64_t)(uint32_t)key * 4u : a.world + nd * 4u;
+  const uint4 *words = a.ident + (uint64_t)i * 2u + ((piece == 1u || piece == 7u) ? 1u : 0u);
+  return column ? reinterpret_cast<const uint4 *>(matrix + (piece - 3u)) : words;
+}
+
+// The part of the piece that does not depend on the output row, from the loaded 16 bytes.
+__device__ __forceinline__ uint4 emit_piece_finish(const EmitArgs &a, uint64_t key, uint32_t i,
+                                                   uint32_t piece, uint4 raw) {
+  // piece 0: mesh.id/.generation, geometry.id/.generation; 3-6: the matrix columns
+  if (piece == 1u) return make_uint4(raw.x, raw.y, raw.z, 1u);  // submesh_index, material, instance_count
   // the sort key as the reference packs it: the low word is source_index + 1
   // (application.h:573-587,657-658)
   if (piece == 2u) return make_uint4(0u, 0u, (uint32_t)(a.index_base + i) + 1u, (uint32_t)(key >> 32));
-  const uint4 id1 = a.ident[(uint64_t)i * 2u + 1u];
-  return make_uint4(encode_scene_object_id(id1.w), 0u, 0u, 0u);
+  if (piece == 7u) return make_uint4(encode_scene_object_id(raw.w), 0u, 0u, 0u);
+  return raw;
+}
+
+__device__ __forceinline__ uint4 emit_piece_gather(const EmitArgs &a, uint64_t key, uint32_t piece) {
+  const uint32_t i = emit_candidate(a, key);
+  const uint64_t nd = (!a.tworld && a.node) ? a.node[i] : i;
+  return emit_piece_finish(a, key, i, piece, *emit_piece_source(a, key, i, nd, piece));
 }
 
 __device__ __forceinline__ void emit_piece_store(const EmitArgs &a, uint32_t row, uint64_t key,
@@ -533,19 +541,62 @@ __device__ __forceinline__ void emit_transparent_piece(const EmitArgs &a, uint32
 
 // Emission from the sorted key array: read backwards when it is ascending; when
 // the last sort pass left it descending, a row's key does not depend on the
-// count and is requested together with it.
+// count and is requested together with it. A block takes EMIT_BATCH x 32
+// consecutive rows, eight lanes per row, and every step of a row's chain of
+// dependent loads (key -> candidate -> node -> 16 bytes) is requested for all of a
+// thread's rows before the first is used: the launch runs beside the next frame's
+// level launches, where a round trip takes several microseconds and a resident
+// block holds a place that a block of those launches would fill.
+constexpr uint32_t EMIT_BATCH = 8;
+constexpr uint32_t EMIT_BLOCK_ROWS = 32u * EMIT_BATCH;
 __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
-  const uint32_t rows_per_block = 256u / 8u;
   const uint32_t piece = threadIdx.x & 7u;
-  const uint32_t stride = gridDim.x * rows_per_block;
-  uint32_t row = blockIdx.x * rows_per_block + (threadIdx.x >> 3);
-  uint64_t key = a.keys[min(row, a.capacity - 1u)];
-  const uint32_t count = a.counters[CNT_TRANSPARENT];
-  for (; row < count; row += stride) {
-    if (!a.keys_descending) key = a.keys[count - 1u - row];
-    const uint64_t next = a.keys[min(row + stride, a.capacity - 1u)];
-    emit_transparent_piece(a, row, key, piece);
-    key = next;
+  const uint32_t group = threadIdx.x >> 3;
+  const uint32_t last_key = a.capacity - 1u;
+  uint32_t base = blockIdx.x * EMIT_BLOCK_ROWS;
+  uint64_t key[EMIT_BATCH];
+#pragma unroll
+  for (uint32_t k = 0; k < EMIT_BATCH; ++k) key[k] = a.keys[min(base + k * 32u + group, last_key)];
+  const uint32_t count = min(a.counters[CNT_TRANSPARENT], a.capacity);
+  for (; base < count; base += gridDim.x * EMIT_BLOCK_ROWS) {  // block-uniform
+    uint32_t row[EMIT_BATCH], cand[EMIT_BATCH];
+    uint64_t nd[EMIT_BATCH];
+    uint4 raw[EMIT_BATCH];
+    bool live[EMIT_BATCH];
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_BATCH; ++k) {
+      row[k] = base + k * 32u + group;
+      live[k] = row[k] < count;
+    }
+    if (!a.keys_descending || base != blockIdx.x * EMIT_BLOCK_ROWS) {
+#pragma unroll
+      for (uint32_t k = 0; k < EMIT_BATCH; ++k) {
+        const uint32_t r = min(row[k], count - 1u);
+        key[k] = a.keys[a.keys_descending ? r : count - 1u - r];
+      }
+    }
+    // rows past the count: their keys are whatever the array holds; they load from
+    // place 0 and store nothing
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_BATCH; ++k) {
+      if (!live[k]) key[k] = 0ull;
+      cand[k] = (uint32_t)key[k];
+    }
+    if (a.tsrc) {
+#pragma unroll
+      for (uint32_t k = 0; k < EMIT_BATCH; ++k) cand[k] = a.tsrc[(uint32_t)key[k]];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_BATCH; ++k) nd[k] = cand[k];
+    if (!a.tworld && a.node) {
+#pragma unroll
+      for (uint32_t k = 0; k < EMIT_BATCH; ++k) nd[k] = a.node[cand[k]];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_BATCH; ++k) raw[k] = *emit_piece_source(a, key[k], cand[k], nd[k], piece);
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_BATCH; ++k)
+      if (live[k]) emit_piece_store(a, row[k], key[k], piece, emit_piece_finish(a, key[k], cand[k], piece, raw[k]));
   }
 }
 

@@ -1740,7 +1740,9 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
     g.states = c->states.p;
     g.visible = c->visible.p;
     g.keys = c->keys_a.p;
-    g.tsrc = c->tsrc.p;
+    // (a tail on the second stream finds the rows' matrices under the candidate index:
+    // the keys carry the candidate and nothing is looked up by place)
+    g.tsrc = c->frame_tail ? nullptr : c->tsrc.p;
     g.world = c->world.p;
     g.node = c->node_identity ? nullptr : c->node.p;
     g.tworld = set_aside ? c->tworld.p : nullptr;
@@ -1817,6 +1819,7 @@ static EmitArgs emit_args(vkrhip_ctx *c, bool set_aside) {
   if (c->frame_tail) {  // the classify blocks set the matrices aside, under the candidate index
     e.world = c->tworld_sparse[c->par].p;
     e.node = nullptr;
+    e.tsrc = nullptr;
   }
   e.ident = c->ident.p;
   e.draws = c->draws.p;
@@ -1885,7 +1888,7 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
     }
     {
       StageTimer timer(c, VKRHIP_TIMER_EMIT, on);
-      const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, 32), 4096);
+      const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, EMIT_BLOCK_ROWS), 4096);
       EmitArgs e = emit_args(c, overlap);
       e.keys_descending = 1u;
       hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, on, e);
