@@ -340,8 +340,16 @@ constexpr int fused_waves(bool has_parent, bool cull, bool room = false) {
   return has_parent ? 4 : (cull ? (room ? 4 : 5) : 6);
 }
 // STAGED: the block expands its segment's survivors itself (segment_finish_staged).
+// KEEP (streaming variants): the launch's nodes have children in a later launch of
+// the frame, which reads their world matrices again as its parents': those are
+// stored without the streaming hint and a part of them is still in the last-level
+// cache when the children ask (16M-node hierarchy, 2M parents of the last level:
+// 557.7 -> 553.6 us; a compile-time variant, because a run-time choice of the store
+// inside store_matrices costs the kernel 85 us of its schedule). The children
+// walking their tiles from the last to the first - the parents written last asked
+// for first - gives the gain away again (558.7 us).
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
-          bool STREAM = false, bool STAGED = false, bool ROOM = false>
+          bool STREAM = false, bool STAGED = false, bool ROOM = false, bool KEEP = false>
 __global__ __launch_bounds__(FUSED_BLOCK)
     __attribute__((amdgpu_waves_per_eu(fused_waves(HAS_PARENT, CULL, ROOM),
                                        fused_waves(HAS_PARENT, CULL, ROOM)))) void
@@ -602,7 +610,7 @@ k_propagate_classify(FusedArgs a) {
     if (valid) *at32(a.t.flags_out + base, t) = (uint8_t)fr;
     {
       const unsigned long long moved = __ballot(did_update);
-      if (moved != 0ull) store_matrices<STREAM>(s_mat, a.t.world, base, w0, w1, w2, w3, moved);  // wave-uniform
+      if (moved != 0ull) store_matrices<STREAM && !KEEP>(s_mat, a.t.world, base, w0, w1, w2, w3, moved);  // wave-uniform
     }
     updated_here += did_update ? 1u : 0u;  // per lane; summed when the block ends
     if (!CULL) continue;  // transform only

@@ -1524,7 +1524,7 @@ static bool frame_streams(const vkrhip_ctx *c) {
 
 template <bool HAS_PARENT, bool TOP = false, bool STREAM = false>
 static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned grid, bool ties,
-                                 bool bounds_out, bool first) {
+                                 bool bounds_out, bool first, bool keep = false) {
   const dim3 g(grid), b(FUSED_BLOCK);
   const size_t lds = TOP ? a.top_lds_offset + top_lds_bytes(c)
                          : cull_shared_bytes(a.c.views);
@@ -1542,6 +1542,11 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
   if (kRootLevel && c->frame_tail && !ties && !bounds_out) {
     launch_timed(c, VKRHIP_TIMER_FUSED, first,
                  k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, kRootLevel>, g, b, lds, a);
+    return;
+  }
+  if (STREAM && !TOP && keep && !ties && !bounds_out) {  // (see KEEP in k_fused.hpp)
+    launch_timed(c, VKRHIP_TIMER_FUSED, first,
+                 k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, false, STREAM && !TOP>, g, b, lds, a);
     return;
   }
   if (ties) {
@@ -1612,12 +1617,14 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     a.c = cull_args(c);
     a.seg_base = (uint32_t)seg_base;
     const bool root = l == 0 || !c->parent.p;
+    // (a later launch of the frame reads this level's world matrices as its parents')
+    const bool keep = (int)l < last_level && c->parent.p;
     if (c->frame_tail && (int)l == last_level) c->attach_stop = c->ev_gathered;
     if (frame_streams(c)) {
       if (root)
-        launch_fused_variant<false, false, true>(c, a, (unsigned)grid, ties, bounds_out, first);
+        launch_fused_variant<false, false, true>(c, a, (unsigned)grid, ties, bounds_out, first, keep);
       else
-        launch_fused_variant<true, false, true>(c, a, (unsigned)grid, ties, bounds_out, first);
+        launch_fused_variant<true, false, true>(c, a, (unsigned)grid, ties, bounds_out, first, keep);
     } else {
       if (root)
         launch_fused_variant<false>(c, a, (unsigned)grid, ties, bounds_out, first);
