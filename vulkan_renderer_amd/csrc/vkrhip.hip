@@ -560,7 +560,12 @@ int check_range(vkrhip_ctx *c, uint64_t first, uint64_t count, uint64_t limit, c
 // whose ranges are wide (parents not ascending with their children) get no
 // plan and run a launch per level.
 constexpr uint64_t kStreamingFootprint = 300ull << 20;  // bytes (measured crossover: about 2M nodes; the last-level cache holds 256 MB)
-constexpr uint32_t kTopMaxTiles = 1024;     // the merged launch covers at most this many tiles
+// The merged launch covers at most this many tiles. A level that joins it saves a
+// launch boundary (the drain of one grid and the cold start of the next, about 10 us
+// on a busy device) and pays for its blocks' ancestor chains (about a tenth of a
+// block's time): the 2049 tiles of a 2M-node level still gain (16M-node hierarchy
+// 552 -> 550 us), all levels in one launch lose (632 us).
+constexpr uint32_t kTopMaxTiles = 3072;
 constexpr uint32_t kTopMaxAncestors = TOP_MAX_ANCESTORS;
 constexpr uint32_t kTopMaxSteps = 24;
 
@@ -1544,9 +1549,9 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
                  k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, kRootLevel>, g, b, lds, a);
     return;
   }
-  if (STREAM && !TOP && keep && !ties && !bounds_out) {  // (see KEEP in k_fused.hpp)
+  if (STREAM && keep && !ties && !bounds_out) {  // (see KEEP in k_fused.hpp)
     launch_timed(c, VKRHIP_TIMER_FUSED, first,
-                 k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, false, STREAM && !TOP>, g, b, lds, a);
+                 k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, false, STREAM>, g, b, lds, a);
     return;
   }
   if (ties) {
@@ -1605,7 +1610,12 @@ static int launch_fused(vkrhip_ctx *c, bool bounds_out) {
     top_args(c, a, cull_shared_bytes(c->views));
     a.seg_base = 0;
     if (c->frame_tail && last_level < 0) c->attach_stop = c->ev_gathered;
-    launch_fused_variant<true, true>(c, a, c->top_blocks, ties, bounds_out, first);
+    // (a large frame streams through the merged levels as well: 16M-node hierarchy 555 -> 552 us;
+    // the launches behind it read the last merged level's world matrices as their parents')
+    if (frame_streams(c) && !ties && !bounds_out && !c->frame_staged && last_level >= 0)
+      launch_fused_variant<true, true, true>(c, a, c->top_blocks, ties, bounds_out, first, true);
+    else
+      launch_fused_variant<true, true>(c, a, c->top_blocks, ties, bounds_out, first);
     first = false;
     seg_base = c->top_blocks;
   }
