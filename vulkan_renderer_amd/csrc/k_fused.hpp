@@ -108,14 +108,20 @@ __device__ __forceinline__ uint32_t in_range_mask(uint32_t rel, uint32_t lo, uin
   return (rel >= lo && rel < hi) ? 0xffffffffu : 0u;
 }
 
-template <bool HAS_PARENT, bool CULL, bool STREAM>
+template <bool HAS_PARENT, bool CULL, bool STREAM, bool STEPS = false>
 __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t tile_base,
                                                  uint32_t lo, uint32_t hi, uint32_t rbase,
                                                  FusedHead &h) {
   const uint32_t rel = clamp_rel(rbase + threadIdx.x, lo, hi);  // < 1024: every offset fits 32 bits
   h.f = load_once<STREAM>(at32(a.t.flags_in + tile_base, rel));
   h.p = NO_PARENT;
-  if (HAS_PARENT) h.p = load_once<STREAM>(at32(a.t.parent + tile_base, rel));
+  if (HAS_PARENT && STEPS) {
+    // the wave's chunk (clamped into the level's part of the tile), lane L word L & 3 of its entry
+    const uint32_t chunk = min(max(rbase + (threadIdx.x & ~63u), lo & ~63u), (hi - 1u) & ~63u) >> 6;
+    h.p = *at32(a.t.parent_steps + (tile_base >> 6) * 4u, chunk * 4u + (threadIdx.x & 3u));
+  } else if (HAS_PARENT) {
+    h.p = load_once<STREAM>(at32(a.t.parent + tile_base, rel));
+  }
   h.ls = f32x4{0.f, 0.f, 0.f, 0.f};
   h.cf = 0u;
   if (CULL) {
@@ -129,11 +135,18 @@ __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t ti
 
 // Waits for the head's loads. Applies the bulk dirty bits and pass 1's clearing
 // of WORLD_UPDATED (vkr_scene_system.c:596) and blanks lanes outside the level.
+template <bool STEPS = false>
 __device__ __forceinline__ void fused_resolve_head(const FusedArgs &a, uint64_t tile_base,
                                                    uint32_t lo, uint32_t hi, uint32_t rbase,
                                                    FusedHead &h) {
   const uint32_t rel = rbase + threadIdx.x;
   uint32_t m = in_range_mask(rel, lo, hi);
+  if (STEPS) {  // first parent of the chunk + the steps up to this lane
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)h.p, 0);
+    const uint32_t steps_lo = (uint32_t)__builtin_amdgcn_readlane((int)h.p, 1);
+    const uint32_t steps_hi = (uint32_t)__builtin_amdgcn_readlane((int)h.p, 2);
+    h.p = first + __builtin_amdgcn_mbcnt_hi(steps_hi, __builtin_amdgcn_mbcnt_lo(steps_lo, 0u));
+  }
   h.f = ((h.f | a.t.force) & ~(uint32_t)F_WORLD_UPDATED) & m & 0xffu;
   h.p |= ~m;  // NO_PARENT outside the level
 }
@@ -289,9 +302,10 @@ __device__ __forceinline__ void own_sgprs(T *&p) {
 }
 __device__ __forceinline__ void own_sgprs(uint64_t &v) { asm volatile("" : "+s"(v)); }
 
-template <bool CULL>
+template <bool CULL, bool STEPS>
 __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
-  own_sgprs(a.t.parent);
+  if (STEPS) own_sgprs(a.t.parent_steps);
+  else own_sgprs(a.t.parent);
   own_sgprs(a.t.pos);
   own_sgprs(a.t.quat);
   own_sgprs(a.t.scale);
@@ -348,8 +362,12 @@ constexpr int fused_waves(bool has_parent, bool cull, bool room = false) {
 // inside store_matrices costs the kernel 85 us of its schedule). The children
 // walking their tiles from the last to the first - the parents written last asked
 // for first - gives the gain away again (558.7 us).
+// STEPS: the level's parents come as a first parent and a step mask per 64 nodes
+// (TransformArgs::parent_steps) instead of an index per node: 4 bytes per node less
+// to read.
 template <bool HAS_PARENT, bool TIES, bool BOUNDS_OUT, bool CULL = true, bool TOP = false,
-          bool STREAM = false, bool STAGED = false, bool ROOM = false, bool KEEP = false>
+          bool STREAM = false, bool STAGED = false, bool ROOM = false, bool KEEP = false,
+          bool STEPS = false>
 __global__ __launch_bounds__(FUSED_BLOCK)
     __attribute__((amdgpu_waves_per_eu(fused_waves(HAS_PARENT, CULL, ROOM),
                                        fused_waves(HAS_PARENT, CULL, ROOM)))) void
@@ -364,7 +382,7 @@ k_propagate_classify(FusedArgs a) {
 
   // (only where it pays: the root-level and tie-counting variants compile to more
   // register traffic with separate values than with the groups)
-  if (HAS_PARENT && !TIES) split_argument_groups<CULL>(a);
+  if (HAS_PARENT && !TIES) split_argument_groups<CULL, STEPS>(a);
   const uint32_t t = threadIdx.x;
   const uint32_t col = t & 3u;
   uint64_t tile_base;
@@ -408,8 +426,8 @@ k_propagate_classify(FusedArgs a) {
   FusedHead head_next, head_after;
   FusedBody body_next;
   FusedParent par_next;
-  if (active(0)) fused_issue_head<HAS_PARENT, CULL, STREAM>(a, tile_base, lo, hi, 0u, head_next);
-  if (active(1)) fused_issue_head<HAS_PARENT, CULL, STREAM>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
+  if (active(0)) fused_issue_head<HAS_PARENT, CULL, STREAM, STEPS>(a, tile_base, lo, hi, 0u, head_next);
+  if (active(1)) fused_issue_head<HAS_PARENT, CULL, STREAM, STEPS>(a, tile_base, lo, hi, FUSED_BLOCK, head_after);
   // merged top levels: thread e < anc_count looks after ancestor entry e
   float4 *anc_world = nullptr;   // [entry][4]: the ancestors' world matrices
   uint32_t *anc_moved = nullptr;  // [entry]: the ancestor's world matrix changes this frame
@@ -425,7 +443,7 @@ k_propagate_classify(FusedArgs a) {
     anc_f = a.t.flags_in[anc_live ? anc_node : 0u];
   }
   if (active(0)) {
-    fused_resolve_head(a, tile_base, lo, hi, 0u, head_next);
+    fused_resolve_head<STEPS>(a, tile_base, lo, hi, 0u, head_next);
     if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
     fused_issue_body<CULL, STREAM>(a, tile_base, lo, hi, 0u, head_next, body_next);
   }
@@ -502,13 +520,13 @@ k_propagate_classify(FusedArgs a) {
     FusedParent par = par_next;
     head_next = head_after;
     if (active(round + 1)) {
-      fused_resolve_head(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
+      fused_resolve_head<STEPS>(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next);
       // ahead of the matrices: loads return in issue order and the window is needed first
       if (HAS_PARENT && !TOP) fused_issue_parent(a, head_next, par_next);
       fused_issue_body<CULL, STREAM>(a, tile_base, lo, hi, rbase + FUSED_BLOCK, head_next, body_next);
     }
     if (active(round + 2))
-      fused_issue_head<HAS_PARENT, CULL, STREAM>(a, tile_base, lo, hi, rbase + 2u * FUSED_BLOCK, head_after);
+      fused_issue_head<HAS_PARENT, CULL, STREAM, STEPS>(a, tile_base, lo, hi, rbase + 2u * FUSED_BLOCK, head_after);
     if (!active(round)) continue;
 
     // ---- columns in: memory layout -> compute layout ----------------------------

@@ -23,6 +23,15 @@ constexpr uint32_t TF_CNT_STRIDE = 8;    // = CNT_COUNT; slot 0 = CNT_NODES_UPDA
 
 struct TransformArgs {
   const uint32_t *parent;  // global array, indexed by node
+  // "Stepping" levels (every node's parent is its predecessor's or the one after
+  // it, as in a breadth-first order with every parent of the level above having a
+  // child): the parents of 64 consecutive nodes are a first parent and a 64-bit
+  // mask - bit k: node k + 1 of the chunk hangs from the next parent - 16 bytes per
+  // chunk instead of 256. Entry of chunk g = (global node index / 64): words
+  // 4 g .. 4 g + 2 of parent_steps (first parent, mask low, mask high); the pointer
+  // is offset per level, and bits below the level's first node in a chunk are 0.
+  // Null: the level reads parent[].
+  const uint32_t *parent_steps;
   const float4 *pos;       // TRS, may be null (locals supplied directly)
   const float4 *quat;
   const float4 *scale;

@@ -62,6 +62,11 @@ struct vkrhip_ctx {
   uint64_t n_nodes = 0;
   std::vector<uint64_t> level_offsets;
   DevBuf<uint32_t> parent;
+  // parents of stepping levels as (first parent, step mask) per 64 nodes, see
+  // TransformArgs::parent_steps; steps_entry[l]: first entry of level l, -1: not stepping
+  DevBuf<uint32_t> parent_steps;
+  std::vector<int64_t> steps_entry;
+  bool steps_enabled = true;  // VKRHIP_PARENT_STEPS=0 keeps the index per node (A/B runs)
   DevBuf<float4> pos, quat, scale;  // lazily allocated
   DevBuf<float4> local, world;
   // SceneTransform.flags, held twice: a frame reads the nodes' flags from one copy
@@ -567,6 +572,7 @@ constexpr uint64_t kStreamingFootprint = 300ull << 20;  // bytes (measured cross
 // 552 -> 550 us), all levels in one launch lose (632 us).
 constexpr uint32_t kTopMaxTiles = 3072;
 constexpr uint32_t kTopMaxAncestors = TOP_MAX_ANCESTORS;
+constexpr uint64_t kStepsMinNodes = 1ull << 20;  // levels below this keep their parent indices
 constexpr uint32_t kTopMaxSteps = 24;
 
 struct TopPlanHost {
@@ -721,6 +727,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   }
   if (const char *env = std::getenv("VKRHIP_TOP_LEVELS")) c->top_enabled = std::atoi(env) != 0;
   if (const char *env = std::getenv("VKRHIP_TOP_BALANCE")) c->top_balance = std::atoi(env) != 0;
+  if (const char *env = std::getenv("VKRHIP_PARENT_STEPS")) c->steps_enabled = std::atoi(env) != 0;
   if (const char *env = std::getenv("VKRHIP_STREAMING")) c->streaming_mode = std::atoi(env) != 0 ? 1 : 0;
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_STAGED")) c->staged_compaction = std::atoi(env);
@@ -807,6 +814,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
     (void)hipEventDestroy(ev.stop);
   }
   dev_free(c->parent);
+  dev_free(c->parent_steps);
   dev_free(c->pos);
   dev_free(c->quat);
   dev_free(c->scale);
@@ -966,6 +974,36 @@ int vkrhip_set_hierarchy(vkrhip_ctx *c, const uint32_t *parent, uint64_t n_nodes
     const uint64_t upto = std::max(n_nodes, c->n_nodes);
     HIP_TRY(c, hipMemcpyAsync(c->flags_other() + from, c->flags() + from, upto - from,
                               hipMemcpyDeviceToDevice, c->stream));
+  }
+  // stepping levels (large ones only: the table saves bytes, and small levels are not bound by theirs)
+  c->steps_entry.assign(levels, -1);
+  if (parent && n_nodes && c->steps_enabled) {
+    std::vector<uint32_t> table;
+    for (uint32_t l = 1; l < levels; ++l) {
+      const uint64_t b = lo[l], e = lo[l + 1];
+      if (e - b < kStepsMinNodes) continue;
+      bool stepping = parent[b] != VKRHIP_NO_PARENT;
+      for (uint64_t i = b + 1; i < e && stepping; ++i)
+        stepping = parent[i] != VKRHIP_NO_PARENT && parent[i] - parent[i - 1] <= 1u;
+      if (!stepping) continue;
+      c->steps_entry[l] = (int64_t)(table.size() / 4u);
+      for (uint64_t g = b / 64u; g <= (e - 1u) / 64u; ++g) {
+        const uint64_t first = std::max(b, g * 64u), end = std::min(e, (g + 1u) * 64u);
+        uint64_t mask = 0;
+        for (uint64_t i = first + 1u; i < end; ++i)
+          if (parent[i] != parent[i - 1]) mask |= 1ull << (i - g * 64u - 1u);
+        table.push_back(parent[first]);
+        table.push_back((uint32_t)mask);
+        table.push_back((uint32_t)(mask >> 32));
+        table.push_back(0u);
+      }
+    }
+    if (!table.empty()) {
+      TRY(dev_alloc(c, c->parent_steps, (c->cfg.max_nodes / 64u + 2u * levels + 2u) * 4u));
+      HIP_TRY(c, hipMemcpyAsync(c->parent_steps.p, table.data(), table.size() * 4u, hipMemcpyHostToDevice,
+                                c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
   }
   c->n_nodes = n_nodes;
   c->level_offsets = lo;
@@ -1341,6 +1379,9 @@ static int launch_encode(vkrhip_ctx *c) {
 static TransformArgs transform_args(vkrhip_ctx *c, uint32_t level) {
   TransformArgs a{};
   a.parent = c->parent.p;
+  a.parent_steps = nullptr;
+  if (level < c->steps_entry.size() && c->steps_entry[level] >= 0)  // indexed by the global chunk
+    a.parent_steps = c->parent_steps.p + (c->steps_entry[level] - (int64_t)(c->level_offsets[level] / 64u)) * 4;
   a.pos = c->have_trs ? c->pos.p : nullptr;
   a.quat = c->quat.p;
   a.scale = c->scale.p;
@@ -1547,6 +1588,16 @@ static void launch_fused_variant(vkrhip_ctx *c, const FusedArgs &a, unsigned gri
   if (kRootLevel && c->frame_tail && !ties && !bounds_out) {
     launch_timed(c, VKRHIP_TIMER_FUSED, first,
                  k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, kRootLevel>, g, b, lds, a);
+    return;
+  }
+  if (STREAM && !TOP && HAS_PARENT && a.t.parent_steps && !ties && !bounds_out) {  // (see STEPS in k_fused.hpp)
+    constexpr bool kSteps = STREAM && !TOP && HAS_PARENT;
+    if (keep)
+      launch_timed(c, VKRHIP_TIMER_FUSED, first,
+                   k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, false, kSteps, kSteps>, g, b, lds, a);
+    else
+      launch_timed(c, VKRHIP_TIMER_FUSED, first,
+                   k_propagate_classify<HAS_PARENT, false, false, true, TOP, STREAM, false, false, false, kSteps>, g, b, lds, a);
     return;
   }
   if (STREAM && keep && !ties && !bounds_out) {  // (see KEEP in k_fused.hpp)
