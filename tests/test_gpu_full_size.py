@@ -127,3 +127,56 @@ def test_config4_shard_thirty_two_million_flat(oracle):
         info = compare_frame(hs, ref, sc)
         assert info.transparent_draw_count > 8192 and info.views[0].visible_count > 500000
         _check_lists(hs, info, sc.n, base=3 * n)
+
+
+def _two_level_scene(roots, parent_of_child, seed=11):
+    """`roots` roots and one child per entry of parent_of_child (ascending root
+    indices): a level large enough for the streaming launches."""
+    synth = _synth()
+    children = parent_of_child.shape[0]
+    n = roots + children
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    parent[roots:] = parent_of_child.astype(np.uint32)
+    offsets = np.array([0, roots, n], np.uint64)
+    index = np.arange(n, dtype=np.uint64)
+    pos_range = np.where(index < roots, np.float32(400.0), np.float32(40.0)).astype(np.float32)
+    pos, quat, scale = synth.make_trs(seed, index, pos_range, (0.9, 1.1))
+    ident, matbits, bounds = synth.make_candidates(seed, index)
+    return synth.Scene(parent, offsets, pos, quat, scale, ident, matbits, bounds, meta={"kind": "deep", "n": n})
+
+
+@pytest.mark.parametrize("shape", ["stepping", "childless_parents", "repeated_runs"])
+def test_large_level_parent_forms(oracle, shape):
+    """A level of 3.4M nodes (too large to join the merged launch of the small
+    levels) that begins in the middle of a 64-node chunk and of a tile. 'stepping': every parent is the predecessor's or the next one (read as a
+    first parent and step masks); 'childless_parents': some roots have no child,
+    so the parents skip (the level keeps its index per node); 'repeated_runs':
+    stepping with runs longer than a chunk and single-child parents mixed."""
+    roots, children = 300_001, 3_400_000
+    j = np.arange(children, dtype=np.uint64)
+    if shape == "stepping":
+        par = (j * np.uint64(roots)) // np.uint64(children)
+    elif shape == "childless_parents":
+        par = (j * np.uint64(roots)) // np.uint64(children)
+        par = np.where(par % np.uint64(7) == 3, par + np.uint64(1), par)  # every seventh root stays childless
+        par = np.minimum(par, np.uint64(roots - 1))
+        par = np.maximum.accumulate(par)
+        assert (np.diff(par.astype(np.int64)) > 1).any()
+    else:
+        rng = np.random.default_rng(5)
+        run = rng.choice(np.array([1, 1, 2, 9, 150, 200], np.int64), size=roots)
+        par = np.repeat(np.arange(roots, dtype=np.uint64), run)[:children]
+        assert par.shape[0] == children and (np.diff(par.astype(np.int64)) <= 1).all()
+    sc = _two_level_scene(roots, par)
+    synth = _synth()
+    vs = synth.camera_views(cascades=1)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, planes.shape[0]) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame()
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert hs.frame_info().nodes_updated == sc.n
