@@ -51,6 +51,8 @@ constexpr uint32_t CF_BUCKET_SHIFT = 4u;      // bits 4..7 state bucket
 constexpr uint32_t CF_BLEND = 0x100u;         // world_transparent
 constexpr uint32_t CF_TRANSMISSIVE = 0x200u;
 constexpr uint32_t CF_UNPUBLISHED = 0x400u;   // omitted by the backend pack: in no GPU view
+static_assert((CF_REF_MASK | (0xfu << CF_BUCKET_SHIFT) | CF_BLEND | CF_TRANSMISSIVE | CF_UNPUBLISHED) <= 0xffffu,
+              "the candidate word has a 16-bit copy");
 
 // device counters (uint32)
 enum : int {
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void k_prepare_candidates(const uint32_t *__re
                                                             const float4 *__restrict__ bounds,
                                                             float4 *__restrict__ sphere,
                                                             uint32_t *__restrict__ cflags,
+                                                            uint16_t *__restrict__ cflags16,
                                                             uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256) void k_prepare_candidates(const uint32_t *__re
   const float hz = (mx.z - mn.z) * 0.5f;
   sphere[i] = make_float4(c.x, c.y, c.z, length3(hx, hy, hz));
   cflags[i] = f;
+  cflags16[i] = (uint16_t)f;
 }
 
 // Floats as unsigned keys in the same order (every finite value maps above 0), so
@@ -157,6 +161,8 @@ struct CullArgs {
   const uint32_t *node;    // candidate -> node, null = identity
   const float4 *sphere;    // local sphere per candidate
   const uint32_t *cflags;  // prepared word per candidate
+  const uint16_t *cflags16;  // the same word in 16 bits (every CF_ bit is below 0x800): what the fused
+                             //   kernel reads, 2 bytes per candidate less
   const float4 *planes;    // views x 6
   const float4 *planes_paired;  // views x 6, planes 2j and 2j+1 interleaved per component
   const float *tie_eps;    // views x 6: eps * max(1,|d|)

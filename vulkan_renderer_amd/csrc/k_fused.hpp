@@ -129,7 +129,7 @@ __device__ __forceinline__ void fused_issue_head(const FusedArgs &a, uint64_t ti
     const uint64_t cbase = min(tile_base, a.c.n - 1u);
     const uint32_t crel = (uint32_t)min((uint64_t)rel, a.c.n - 1u - cbase);
     h.ls = load_once<STREAM>(at32(reinterpret_cast<const f32x4 *>(a.c.sphere) + cbase, crel));
-    h.cf = load_once<STREAM>(at32(a.c.cflags + cbase, crel));
+    h.cf = load_once<STREAM>(at32(a.c.cflags16 + cbase, crel));
   }
 }
 
@@ -318,7 +318,7 @@ __device__ __forceinline__ void split_argument_groups(FusedArgs &a) {
   own_sgprs(a.t.end);
   if (CULL) {
     own_sgprs(a.c.sphere);
-    own_sgprs(a.c.cflags);
+    own_sgprs(a.c.cflags16);
     own_sgprs(a.c.planes);
     own_sgprs(a.c.planes_paired);
     own_sgprs(a.c.tie_eps);

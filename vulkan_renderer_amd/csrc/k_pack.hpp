@@ -56,6 +56,7 @@ struct PackResolveArgs {
   const SubmeshRange *submeshes;
   const MaterialEntry *materials;
   uint32_t *cflags;
+  uint16_t *cflags16;  // (the copy the fused kernel reads)
   uint4 *pack_a;     // geometry_index, material_index, first_index, index_count
   int32_t *pack_vo;  // vertex_offset
   uint8_t *status;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void k_pack_resolve(PackResolveArgs a) {
   a.pack_vo[i] = vertex_offset;
   const uint32_t cf = a.cflags[i] & ~CF_UNPUBLISHED;
   a.cflags[i] = status == PACK_OK ? cf : (cf | CF_UNPUBLISHED);
+  a.cflags16[i] = (uint16_t)(status == PACK_OK ? cf : (cf | CF_UNPUBLISHED));
 }
 
 // Packed index of every candidate (exclusive prefix over the rows that

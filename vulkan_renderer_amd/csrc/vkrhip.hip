@@ -103,6 +103,7 @@ struct vkrhip_ctx {
   DevBuf<uint4> ident;
   DevBuf<float4> sphere;
   DevBuf<uint32_t> cflags;
+  DevBuf<uint16_t> cflags16;
   uint64_t blend_rows = 0;  // rows that can enter the transparent list
   uint64_t tcap = 0;        // allocated transparent capacity
 
@@ -759,6 +760,7 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->ident, mc * 2));
     TRY(dev_alloc(c, c->sphere, mc));
     TRY(dev_alloc(c, c->cflags, mc));
+    TRY(dev_alloc(c, c->cflags16, mc));
     TRY(dev_alloc(c, c->planes, VKRHIP_MAX_VIEWS * 6));
     TRY(dev_alloc(c, c->planes_paired, VKRHIP_MAX_VIEWS * 6));
     TRY(dev_alloc(c, c->tie_eps, VKRHIP_MAX_VIEWS * 6));
@@ -829,6 +831,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   dev_free(c->ident);
   dev_free(c->sphere);
   dev_free(c->cflags);
+  dev_free(c->cflags16);
   dev_free(c->planes);
   dev_free(c->planes_paired);
   dev_free(c->tie_eps);
@@ -1188,7 +1191,7 @@ int vkrhip_set_candidates(vkrhip_ctx *c, uint64_t n, const uint32_t *node, const
       e = hipMemcpyAsync(d_bounds.p, bounds, n * 48, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_prepare_candidates, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
-                         c->stream, d_mat.p, d_bounds.p, c->sphere.p, c->cflags.p, n);
+                         c->stream, d_mat.p, d_bounds.p, c->sphere.p, c->cflags.p, c->cflags16.p, n);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1304,6 +1307,7 @@ int vkrhip_set_publication(vkrhip_ctx *c, const vkrhip_geometry_entry *geometrie
     a.submeshes = c->pub_submeshes.p;
     a.materials = c->pub_materials.p;
     a.cflags = c->cflags.p;
+    a.cflags16 = c->cflags16.p;
     a.pack_a = c->pack_a.p;
     a.pack_vo = c->pack_vo.p;
     a.status = c->pack_status.p;
@@ -1402,6 +1406,7 @@ static CullArgs cull_args(vkrhip_ctx *c) {
   a.node = c->node_identity ? nullptr : c->node.p;
   a.sphere = c->sphere.p;
   a.cflags = c->cflags.p;
+  a.cflags16 = c->cflags16.p;
   a.planes = c->planes.p;
   a.planes_paired = c->planes_paired.p;
   a.tie_eps = c->tie_eps.p;
