@@ -1838,6 +1838,12 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
 
 // Hierarchies below this size keep the transparent sort on the frame's stream.
 constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
+// ... and below this size the whole tail. A frame with its tail on the second stream
+// costs the host three stream-waits and an event more (about 36 us per frame against
+// 12), which sets the pace below roughly 40 us of device time per frame: 1M flat
+// nodes with one view 42.1 -> 40.7 us, 786K 36.1 -> 39.6 us; a 1M-node hierarchy of
+// depth 8 with five views 182 -> 122 us, 3M nodes 275 -> 206 us.
+constexpr uint64_t TAIL_MIN_NODES = 1000000ull;
 
 // Whether the frame's transparent sort and emission go to the second stream,
 // beside the next frame's transform. They must then read nothing that transform
@@ -1877,7 +1883,7 @@ static bool tail_on_second_stream(const vkrhip_ctx *c, uint32_t stages, bool fus
   if (!fused || !second_stream_usable(c) || !(stages & VKRHIP_STAGE_TRANSPARENT)) return false;
   if (stages & (VKRHIP_STAGE_CANDIDATES | VKRHIP_STAGE_PACK | VKRHIP_STAGE_ENCODE)) return false;
   if (c->overlap_tail >= 2) return true;
-  return c->overlap_tail == 1 && c->overlap_sort != 0 && c->n_nodes >= OVERLAP_MIN_NODES &&
+  return c->overlap_tail == 1 && c->overlap_sort != 0 && c->n_nodes >= TAIL_MIN_NODES &&
          c->views <= TAIL_MAX_VIEWS;
 }
 
