@@ -76,13 +76,20 @@ def staged_mode(request, monkeypatch):
     return request.param
 
 
-@pytest.fixture(params=["default", "tail"])
+@pytest.fixture(params=["default", "tail", "tail_one_thread", "tail_events"])
 def tail_mode(request, monkeypatch):
-    """Runs a test twice: as the library decides by itself (small scenes keep the
-    whole frame on one stream) and with VKRHIP_OVERLAP_TAIL=2, where every frame the
-    fused kernel serves puts scan, gather, sort and emission on the second stream
-    and the next frame starts right behind the classify (what large hierarchies do
-    by default). The switch is read when a context is created."""
-    if request.param == "tail":
+    """Runs a test several times: as the library decides by itself (small scenes keep
+    the whole frame on one stream) and with VKRHIP_OVERLAP_TAIL=2, where every frame
+    the fused kernel serves puts scan, gather, sort and emission on the second stream
+    and the next frame starts right behind the classify (what scenes of 1M nodes and
+    more do by default) - with the tail enqueued by the context's worker thread and
+    the streams ordered by signal and gate kernels (the default), with the calling
+    thread enqueuing everything (VKRHIP_TAIL_WORKER=0), and with events between the
+    streams (VKRHIP_SIDE_GATE=0). The switches are read when a context is created."""
+    if request.param != "default":
         monkeypatch.setenv("VKRHIP_OVERLAP_TAIL", "2")
+    if request.param == "tail_one_thread":
+        monkeypatch.setenv("VKRHIP_TAIL_WORKER", "0")
+    if request.param == "tail_events":
+        monkeypatch.setenv("VKRHIP_SIDE_GATE", "0")
     return request.param

@@ -57,4 +57,27 @@ __global__ __launch_bounds__(256) void k_or_flags(uint8_t *flags_a, uint8_t *fla
   flags_b[first + i] |= bits;
 }
 
+// Ordering between the context's two streams without a wait packet. A stream-wait
+// between two level launches costs the device 8.5 us even when the event was
+// recorded long ago (the queue drains, the packet is evaluated, the next launch
+// starts cold); two tiny kernels cost a third of that: the batch on the second
+// stream ends with k_side_signal, which publishes the batch's serial number, and
+// the context's stream runs k_side_gate - one wave that returns once the serial
+// has arrived, normally at its first look - ahead of the launch that must come
+// behind the batch. Kernel boundaries on either side make the batch's writes
+// visible to that launch as they do between any two launches.
+__global__ __launch_bounds__(64) void k_side_signal(uint64_t *flag, uint64_t serial) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// (A gate that has looked 2^22 times - seconds - gives up, so that the grid always
+// drains, and leaves a mark in *stalled that vkrhip_get_frame_info reports.)
+__global__ __launch_bounds__(64) void k_side_gate(const uint64_t *flag, uint64_t serial, uint64_t *stalled) {
+  if (threadIdx.x != 0) return;
+  for (uint32_t looks = 0; looks < (1u << 22); ++looks) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= serial) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_store(stalled, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace vkr

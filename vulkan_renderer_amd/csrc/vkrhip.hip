@@ -10,6 +10,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +53,44 @@ struct DevBuf {
 };
 
 }  // namespace
+
+// The tail of a frame enqueued by a second host thread. With the tail on the second
+// stream a frame costs the host a stream-wait, three or more launches and an event
+// record beyond the level launches - 38 us per frame where the device needs 31 (1M
+// nodes) - and none of those calls depends on anything the calling thread does
+// next. The calling thread therefore only DESCRIBES them (kernel, grid, a copy of
+// the arguments) and a worker thread of the context issues them on the second
+// stream, in order, while the caller is already preparing the next frame. Every
+// other entry point waits for the worker to be idle first (bind_device), so
+// outside vkrhip_frame the second stream is exactly where a single thread would
+// have left it.
+struct TailLaunch {
+  const void *fn = nullptr;
+  dim3 grid, block;
+  uint32_t lds = 0, nparams = 0;
+  uint32_t offset[3] = {0, 0, 0};
+  alignas(16) unsigned char blob[448];
+};
+struct TailJob {
+  hipEvent_t wait = nullptr;    // the second stream waits for this first
+  hipEvent_t record = nullptr;  // ... and records this behind the launches
+  uint32_t n = 0;
+  bool overflow = false;  // more launches than the job holds: the frame fails (never seen)
+  static constexpr uint32_t kLaunches = 12;  // scan, gather, histogram, four passes, emission, signal
+  TailLaunch launch[kLaunches];
+};
+struct TailWorker {
+  std::thread thread;
+  std::mutex m;
+  std::condition_variable cv;
+  TailJob ring[4];
+  std::atomic<uint64_t> pushed{0}, done{0};
+  std::atomic<bool> stop{false}, sleeping{false};
+  std::atomic<int> error{0};  // the first hipError_t a job met
+  hipStream_t stream = nullptr;
+  int device = 0;
+  uint64_t busy_ns = 0, jobs = 0;  // (read after the thread has ended)
+};
 
 struct vkrhip_ctx {
   vkrhip_config cfg{};
@@ -246,6 +287,19 @@ struct vkrhip_ctx {
   hipStream_t tstream = nullptr;
   hipEvent_t attach_stop = nullptr;  // recorded by the next heavy launch itself, as its completion signal
   hipEvent_t ev_gathered = nullptr;  // main stream: what the side stream's work of the frame reads is complete
+  hipEvent_t ev_gathered2[2] = {nullptr, nullptr};  // (frames alternate: a worker may still have to enqueue the
+  uint32_t gathered_turn = 0;                       //  wait for the previous frame's)
+  TailWorker *worker = nullptr;
+  TailJob *building = nullptr;     // launches on the second stream are described into this job
+  int worker_mode = 1;             // VKRHIP_TAIL_WORKER=0: the calling thread enqueues the tail itself
+  // Batches of second-stream work are numbered; side_flag[k] holds the serial of the
+  // last batch behind ev_side[k] that is over (k_side_signal / k_side_gate, k_transform.hpp).
+  // VKRHIP_SIDE_GATE=0: the context's stream waits for the event instead.
+  DevBuf<uint64_t> side_flag;
+  uint64_t side_serial = 0;
+  uint64_t side_expected[2] = {0, 0};
+  int side_gate = 1;
+  uint64_t side_job[2] = {0, 0};   // the job that records ev_side[k] (0: recorded by the calling thread)
   // Side stream: everything a frame put there is done. One event per copy `par`, so
   // that a wait that is still queued never sees its event recorded again.
   hipEvent_t ev_side[2] = {nullptr, nullptr};
@@ -334,9 +388,158 @@ void dev_free(DevBuf<T> &b) {
   b.count = 0;
 }
 
-int bind_device(vkrhip_ctx *c) {
-  HIP_TRY(c, hipSetDevice(c->device));
+void cpu_relax() { __builtin_ia32_pause(); }
+
+void tail_worker_main(TailWorker *w) {
+  (void)hipSetDevice(w->device);
+  uint64_t next = 0;
+  uint32_t idle = 0;
+  for (;;) {
+    if (w->pushed.load(std::memory_order_acquire) > next) {
+      const TailJob &job = w->ring[next & 3u];
+      timespec t0, t1;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      hipError_t e = hipSuccess;
+      if (job.wait) e = hipStreamWaitEvent(w->stream, job.wait, 0);
+      for (uint32_t k = 0; k < job.n && e == hipSuccess; ++k) {
+        const TailLaunch &l = job.launch[k];
+        void *argv[3] = {(void *)(l.blob + l.offset[0]), (void *)(l.blob + l.offset[1]),
+                         (void *)(l.blob + l.offset[2])};
+        e = hipLaunchKernel(l.fn, l.grid, l.block, argv, l.lds, w->stream);
+      }
+      if (e == hipSuccess && job.record) e = hipEventRecord(job.record, w->stream);
+      if (e != hipSuccess) {
+        int none = 0;
+        w->error.compare_exchange_strong(none, (int)e);
+      }
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      w->busy_ns += (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+      ++w->jobs;
+      ++next;
+      w->done.store(next, std::memory_order_release);
+      idle = 0;
+      continue;
+    }
+    if (w->stop.load(std::memory_order_acquire)) return;
+    if (++idle < 200000u) {  // frames arrive tens of microseconds apart: spin between them
+      cpu_relax();
+      continue;
+    }
+    std::unique_lock<std::mutex> lock(w->m);  // nothing for a while: sleep
+    w->sleeping.store(true, std::memory_order_seq_cst);
+    w->cv.wait_for(lock, std::chrono::milliseconds(20), [&] {
+      return w->pushed.load(std::memory_order_acquire) > next || w->stop.load(std::memory_order_acquire);
+    });
+    w->sleeping.store(false, std::memory_order_seq_cst);
+    idle = 0;
+  }
+}
+
+int worker_error(vkrhip_ctx *c) {
+  const int e = c->worker->error.exchange(0);
+  if (e)
+    return fail(c, VKRHIP_ERR_HIP, "a launch on the second stream failed: %s", hipGetErrorString((hipError_t)e));
   return VKRHIP_OK;
+}
+
+// Waits until the worker has issued job `serial` (jobs count from 1).
+int worker_wait(vkrhip_ctx *c, uint64_t serial) {
+  if (!c->worker) return VKRHIP_OK;
+  while (c->worker->done.load(std::memory_order_acquire) < serial) cpu_relax();
+  return worker_error(c);
+}
+int worker_flush(vkrhip_ctx *c) {
+  return c->worker ? worker_wait(c, c->worker->pushed.load(std::memory_order_relaxed)) : VKRHIP_OK;
+}
+
+int worker_start(vkrhip_ctx *c) {
+  if (c->worker) return VKRHIP_OK;
+  c->worker = new (std::nothrow) TailWorker();
+  if (!c->worker) return fail(c, VKRHIP_ERR_HIP, "out of host memory");
+  c->worker->stream = c->tstream;
+  c->worker->device = c->device;
+  c->worker->thread = std::thread(tail_worker_main, c->worker);
+  return VKRHIP_OK;
+}
+
+// The job the calling thread fills next (at most two are ahead of the worker).
+TailJob *worker_begin(vkrhip_ctx *c) {
+  TailWorker *w = c->worker;
+  const uint64_t pushed = w->pushed.load(std::memory_order_relaxed);
+  while (pushed - w->done.load(std::memory_order_acquire) >= 2u) cpu_relax();
+  TailJob *job = &w->ring[pushed & 3u];
+  job->wait = job->record = nullptr;
+  job->n = 0;
+  job->overflow = false;
+  return job;
+}
+void worker_push(vkrhip_ctx *c) {
+  TailWorker *w = c->worker;
+  w->pushed.fetch_add(1, std::memory_order_release);
+  if (w->sleeping.load(std::memory_order_seq_cst)) {
+    std::lock_guard<std::mutex> lock(w->m);
+    w->cv.notify_one();
+  }
+}
+void worker_stop(vkrhip_ctx *c) {
+  if (!c->worker) return;
+  while (c->worker->done.load(std::memory_order_acquire) < c->worker->pushed.load(std::memory_order_relaxed))
+    cpu_relax();
+  c->worker->stop.store(true, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lock(c->worker->m);
+    c->worker->cv.notify_one();
+  }
+  if (c->worker->thread.joinable()) c->worker->thread.join();
+  if ((c->xdebug & 1) && c->worker->jobs)
+    std::fprintf(stderr, "tail worker: %llu jobs, %.1f us each\n", (unsigned long long)c->worker->jobs,
+                 c->worker->busy_ns / 1e3 / c->worker->jobs);
+  delete c->worker;
+  c->worker = nullptr;
+}
+
+// `flush`: the worker thread has issued everything it was given (every entry point
+// but vkrhip_frame: what they do with the streams comes behind it).
+int bind_device(vkrhip_ctx *c, bool flush = true) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (flush && c->worker) return worker_flush(c);
+  return VKRHIP_OK;
+}
+
+// A kernel launch on `on`; while a job for the worker is being described and `on`
+// is the second stream, the launch goes into the job instead.
+template <typename T>
+struct as_given {
+  using type = T;
+};
+template <typename... P>
+void launch_on(vkrhip_ctx *c, hipStream_t on, void (*kernel)(P...), dim3 grid, dim3 block, size_t lds,
+               typename as_given<P>::type... args) {
+  static_assert(sizeof...(P) >= 1 && sizeof...(P) <= 3, "launches described for the worker");
+  if (c->building && on == c->tstream) {
+    if (c->building->n >= TailJob::kLaunches) {
+      c->building->overflow = true;
+      return;
+    }
+    TailLaunch &l = c->building->launch[c->building->n++];
+    l.fn = reinterpret_cast<const void *>(kernel);
+    l.grid = grid;
+    l.block = block;
+    l.lds = (uint32_t)lds;
+    l.nparams = (uint32_t)sizeof...(P);
+    size_t off = 0;
+    uint32_t k = 0;
+    auto put = [&](const void *src, size_t size, size_t align) {
+      off = (off + align - 1) / align * align;
+      std::memcpy(l.blob + off, src, size);
+      l.offset[k++] = (uint32_t)off;
+      off += size;
+    };
+    static_assert((sizeof(P) + ...) + 32 <= sizeof(l.blob), "argument copy");
+    (put(&args, sizeof(P), alignof(P)), ...);
+    return;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, on, args...);
 }
 
 #define TRY(expr)                    \
@@ -452,9 +655,17 @@ struct StageTimer {
 // wait; the host does not block). Called wherever the main stream, or the host
 // through it, is about to read the draws or to change what the emission reads.
 int join_side(vkrhip_ctx *c) {
+  TRY(worker_flush(c));
   // (the side stream runs in order: behind its last event nothing of it is left)
   if (c->side_last >= 0 && c->side_pending[c->side_last]) {
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[c->side_last], 0));
+    const int e = c->side_last;
+    if (c->side_expected[e]) {
+      hipLaunchKernelGGL(k_side_gate, dim3(1), dim3(64), 0, c->stream, (const uint64_t *)c->side_flag.p + e,
+                         c->side_expected[e], c->side_flag.p + 2);
+      HIP_TRY(c, hipGetLastError());
+    } else {
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[e], 0));
+    }
     c->side_pending[0] = c->side_pending[1] = false;
   }
   return VKRHIP_OK;
@@ -466,7 +677,16 @@ int join_side(vkrhip_ctx *c) {
 int wait_side_event(vkrhip_ctx *c, int e) {
   if (e < 0) return VKRHIP_OK;
   if (c->side_pending[e]) {
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[e], 0));
+    if (c->side_expected[e]) {
+      // (needs nothing of the worker: the gate passes once the batch's signal has run,
+      // whenever that is enqueued)
+      hipLaunchKernelGGL(k_side_gate, dim3(1), dim3(64), 0, c->stream, (const uint64_t *)c->side_flag.p + e,
+                         c->side_expected[e], c->side_flag.p + 2);
+      HIP_TRY(c, hipGetLastError());
+    } else {
+      TRY(worker_wait(c, c->side_job[e]));  // (the record has to be enqueued before the wait)
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side[e], 0));
+    }
     c->side_pending[e] = false;
     if (c->side_last == e) c->side_pending[e ^ 1] = false;  // recorded earlier: covered as well
   }
@@ -476,7 +696,17 @@ int wait_side_event(vkrhip_ctx *c, int e) {
 // Marks the end of a batch of side-stream work. Returns the event's index.
 int record_side(vkrhip_ctx *c, int *out_event) {
   const int e = (int)c->side_turn;
-  HIP_TRY(c, hipEventRecord(c->ev_side[e], c->tstream));
+  c->side_expected[e] = 0;
+  c->side_job[e] = c->building ? c->worker->pushed.load(std::memory_order_relaxed) + 1u : 0u;
+  if (c->side_gate && c->side_flag.p) {  // the batch ends with its signal (no event)
+    c->side_expected[e] = ++c->side_serial;
+    launch_on(c, c->tstream, k_side_signal, dim3(1), dim3(64), 0, c->side_flag.p + e, c->side_expected[e]);
+    if (!c->building) HIP_TRY(c, hipGetLastError());
+  } else if (c->building) {  // the worker records the event behind the job's launches
+    c->building->record = c->ev_side[e];
+  } else {
+    HIP_TRY(c, hipEventRecord(c->ev_side[e], c->tstream));
+  }
   c->side_pending[e] = true;
   c->side_last = e;
   c->side_turn ^= 1u;
@@ -487,6 +717,7 @@ int record_side(vkrhip_ctx *c, int *out_event) {
 // The host waits for the side stream (entry points that free or rewrite what its
 // kernels read).
 int drain_side(vkrhip_ctx *c) {
+  TRY(worker_flush(c));
   if (c->tstream) HIP_TRY(c, hipStreamSynchronize(c->tstream));
   c->side_pending[0] = c->side_pending[1] = false;
   return VKRHIP_OK;
@@ -733,6 +964,8 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   if (const char *env = std::getenv("VKRHIP_OVERLAP_SORT")) c->overlap_sort = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_STAGED")) c->staged_compaction = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_OVERLAP_TAIL")) c->overlap_tail = std::atoi(env);
+  if (const char *env = std::getenv("VKRHIP_TAIL_WORKER")) c->worker_mode = std::atoi(env);
+  if (const char *env = std::getenv("VKRHIP_SIDE_GATE")) c->side_gate = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_XDEBUG")) c->xdebug = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
   int rc = VKRHIP_OK;
@@ -746,7 +979,8 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->tstream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
+    for (auto &e : c->ev_gathered2) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_gathered = c->ev_gathered2[0];
     for (auto &e : c->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const uint64_t mn = c->cfg.max_nodes, mc = std::max<uint64_t>(c->cfg.max_candidates, 1);
     TRY(dev_alloc(c, c->local, mn * 4));
@@ -767,6 +1001,8 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
     TRY(dev_alloc(c, c->required, VKRHIP_MAX_VIEWS));
     TRY(dev_alloc(c, c->camera_view, 4));
     TRY(dev_alloc(c, c->tvis, mc));
+    TRY(dev_alloc(c, c->side_flag, 3));  // (two flags and the gates' stall mark)
+    HIP_TRY(c, hipMemsetAsync(c->side_flag.p, 0, 3 * sizeof(uint64_t), c->stream));
     TRY(dev_alloc(c, c->frame_zero, vkrhip_ctx::kBlocks * vkrhip_ctx::kBlockBytes));
     HIP_TRY(c, hipMemsetAsync(c->frame_zero.p, 0, c->frame_zero.count, c->stream));
     TRY(dev_alloc(c, c->tkey2[0], mc));
@@ -795,10 +1031,14 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
 void vkrhip_destroy(vkrhip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  worker_stop(c);
   if (c->tstream) (void)hipStreamSynchronize(c->tstream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->tstream) (void)hipStreamDestroy(c->tstream);
-  if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+  for (auto &e : c->ev_gathered2) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
   for (auto &e : c->ev_side) {
     if (e) (void)hipEventDestroy(e);
     e = nullptr;
@@ -806,6 +1046,7 @@ void vkrhip_destroy(vkrhip_ctx *c) {
   c->tstream = nullptr;
   c->ev_gathered = nullptr;
   dev_free(c->tsrc);
+  dev_free(c->side_flag);
   dev_free(c->tworld);
   for (EventPair &ev : c->pending) {
     (void)hipEventDestroy(ev.start);
@@ -1794,9 +2035,9 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
     s.clear = reinterpret_cast<uint32_t *>(c->counter_block(next_block));
     s.clear_words = (uint32_t)(vkrhip_ctx::kBlockBytes / sizeof(uint32_t));
     if (segments <= 4096u)
-      hipLaunchKernelGGL(k_scan<256>, dim3(c->views * 4u + 1u), dim3(256), 0, on, s);
+      launch_on(c, on, k_scan<256>, dim3(c->views * 4u + 1u), dim3(256), 0, s);
     else
-      hipLaunchKernelGGL(k_scan<SCAN_BLOCK>, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, on, s);
+      launch_on(c, on, k_scan<SCAN_BLOCK>, dim3(c->views * 4u + 1u), dim3(SCAN_BLOCK), 0, s);
     HIP_TRY(c, hipGetLastError());
     c->block_clean[next_block] = true;
   }
@@ -1829,8 +2070,8 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
     g.partition_capacity = c->cfg.partition_capacity;
     // (a wave of k_gather takes one segment, a wave of k_place PLACE_SEGS)
     const unsigned grid = (unsigned)ceil_div(segments, (GATHER_BLOCK / 64) * (c->frame_staged ? PLACE_SEGS : 1u));
-    hipLaunchKernelGGL(c->frame_staged ? k_place : (c->views > GATHER_MANY_VIEWS ? k_gather_many : k_gather),
-                       dim3(grid), dim3(GATHER_BLOCK), 0, on, g);
+    launch_on(c, on, c->frame_staged ? k_place : (c->views > GATHER_MANY_VIEWS ? k_gather_many : k_gather),
+              dim3(grid), dim3(GATHER_BLOCK), 0, g);
     HIP_TRY(c, hipGetLastError());
   }
   return VKRHIP_OK;
@@ -1934,8 +2175,8 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
   if (expected <= RANK_LIMIT) {
     StageTimer timer(c, VKRHIP_TIMER_SORT, on);
     const unsigned grid = (unsigned)std::max<uint64_t>(1, ceil_div(expected, (uint64_t)RANK_BLOCK_KEYS));
-    hipLaunchKernelGGL(k_rank_emit, dim3(grid), dim3(SMALL_THREADS), 0, on, emit_args(c, overlap), c->keys_a.p,
-                       c->keys_b.p);
+    launch_on(c, on, k_rank_emit, dim3(grid), dim3(SMALL_THREADS), 0, emit_args(c, overlap), c->keys_a.p,
+              c->keys_b.p);
     HIP_TRY(c, hipGetLastError());
   } else {
     {
@@ -1953,14 +2194,14 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
       s.serial = c->sort_serial;
       s.capacity = (uint32_t)c->tcap;
       s.keys_in = c->keys_a.p;
-      hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(SORT_BLOCK), 0, on, s);
+      launch_on(c, on, k_sort_hist, dim3(grid), dim3(SORT_BLOCK), 0, s);
       bool in_a = true;
       for (uint32_t pass = 0; pass < (uint32_t)SORT_PASSES; ++pass) {  // four passes end in keys_a again
         s.keys_in = in_a ? c->keys_a.p : c->keys_b.p;
         s.keys_out = in_a ? c->keys_b.p : c->keys_a.p;
         s.pass = pass;
         s.descending = pass + 1u == (uint32_t)SORT_PASSES;  // the draw order is back to front
-        hipLaunchKernelGGL(k_sort_pass, dim3(grid), dim3(SORT_BLOCK), 0, on, s);
+        launch_on(c, on, k_sort_pass, dim3(grid), dim3(SORT_BLOCK), 0, s);
         in_a = !in_a;
       }
       HIP_TRY(c, hipGetLastError());
@@ -1970,7 +2211,7 @@ static int launch_transparent(vkrhip_ctx *c, bool overlap) {
       const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(expected, EMIT_BLOCK_ROWS), 4096);
       EmitArgs e = emit_args(c, overlap);
       e.keys_descending = 1u;
-      hipLaunchKernelGGL(k_emit_transparent, dim3(grid), dim3(256), 0, on, e);
+      launch_on(c, on, k_emit_transparent, dim3(grid), dim3(256), 0, e);
       HIP_TRY(c, hipGetLastError());
     }
   }
@@ -2063,7 +2304,7 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
                   "candidate rows name node %llu but the scene has %llu nodes: bind the rows again",
                   (unsigned long long)(named - 1u), (unsigned long long)nodes);
   }
-  TRY(bind_device(c));
+  TRY(bind_device(c, false));
   c->frame_stages = stages;
   const bool cull = (stages & VKRHIP_STAGE_CULL) != 0;
   const bool bounds_out = (stages & VKRHIP_STAGE_WORLD_BOUNDS) != 0;
@@ -2089,7 +2330,24 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     const bool fused = cull && c->hzb_mips == 0 && (stages & VKRHIP_STAGE_TRANSFORM) && c->node_identity &&
                        c->n_cand > 0 && c->n_cand <= c->n_nodes && c->level_offsets.size() > 1;
     c->frame_tail = tail_on_second_stream(c, stages, fused);
-    if (c->frame_tail) TRY(ensure_tail_buffers(c));
+    // A frame that does not leave its tail to the worker thread finds the second
+    // stream as a single thread would have left it.
+    constexpr uint32_t kTailTimers = (1u << VKRHIP_TIMER_SCAN) | (1u << VKRHIP_TIMER_SCATTER) |
+                                     (1u << VKRHIP_TIMER_SORT) | (1u << VKRHIP_TIMER_EMIT);
+    const bool to_worker = c->frame_tail && c->worker_mode != 0 && !(c->profiling & kTailTimers);
+    if (!to_worker) TRY(worker_flush(c));
+    if (c->frame_tail) {
+      TRY(ensure_tail_buffers(c));
+      // The frame's last level launch records the event that the tail of two frames
+      // ago waited for: that wait must have been enqueued (a worker that lags two jobs
+      // would make that tail wait for THIS frame, which waits for that tail's signal).
+      if (c->worker) {
+        const uint64_t pushed = c->worker->pushed.load(std::memory_order_relaxed);
+        if (pushed > 1u) TRY(worker_wait(c, pushed - 1u));
+      }
+      c->gathered_turn ^= 1u;
+      c->ev_gathered = c->ev_gathered2[c->gathered_turn];
+    }
     if (cull) {
       // frames alternate between the copies of the segment tables; the batch of
       // side-stream work that read this frame's copy must be over before the
@@ -2108,9 +2366,31 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     if (c->frame_tail) {
       // the tail waits for the classify on the second stream (ev_gathered is the last
       // classify launch's own completion signal); the frame's stream goes on
-      HIP_TRY(c, hipStreamWaitEvent(c->tstream, c->ev_gathered, 0));
-      TRY(launch_compaction(c, false, c->tstream));
-      TRY(launch_transparent(c, true));
+      if (to_worker) {
+        TRY(worker_start(c));
+        TailJob *job = worker_begin(c);
+        job->wait = c->ev_gathered;
+        c->building = job;
+        int rc = launch_compaction(c, false, c->tstream);
+        if (rc == VKRHIP_OK) rc = launch_transparent(c, true);
+        c->building = nullptr;
+        if (rc == VKRHIP_OK && job->overflow) rc = fail(c, VKRHIP_ERR_STATE, "too many launches in one tail job");
+        if (rc != VKRHIP_OK) {  // the job is dropped: nothing may wait for its signal
+          const uint64_t dropped = c->worker->pushed.load(std::memory_order_relaxed) + 1u;
+          for (int k = 0; k < 2; ++k)
+            if (c->side_job[k] == dropped) {
+              c->side_job[k] = 0;
+              c->side_expected[k] = 0;
+              c->side_pending[k] = false;
+            }
+          return rc;
+        }
+        worker_push(c);
+      } else {
+        HIP_TRY(c, hipStreamWaitEvent(c->tstream, c->ev_gathered, 0));
+        TRY(launch_compaction(c, false, c->tstream));
+        TRY(launch_transparent(c, true));
+      }
     } else {
       // the previous frame's work on the side stream still owns the previous counter
       // block, the key buffers, the lists and the set-aside rows: the scan zeroes
@@ -2159,7 +2439,14 @@ int vkrhip_get_frame_info(vkrhip_ctx *c, vkrhip_frame_info *out) try {
                             c->counter_block(c->sort_block) + vkrhip_ctx::kCountersBytes +
                                 vkrhip_ctx::kTiesBytes + offsetof(SortState, stalled),
                             sizeof(sort_stalled), hipMemcpyDeviceToHost, c->stream));
+  uint64_t gate_stalled = 0;
+  HIP_TRY(c, hipMemcpyAsync(&gate_stalled, c->side_flag.p + 2, sizeof(gate_stalled), hipMemcpyDeviceToHost,
+                            c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (gate_stalled)
+    return fail(c, VKRHIP_ERR_STATE,
+                "a level launch gave up waiting for batch %llu of second-stream work and ran ahead of it",
+                (unsigned long long)gate_stalled);
   if (sort_stalled[0])
     return fail(c, VKRHIP_ERR_STATE,
                 "the draw-key sort gave up waiting for another tile's prefix (pass %u, digit %u: tile %u "
@@ -2952,7 +3239,16 @@ int vkrhip_exchange_run(vkrhip_ctx *c) {
   }
   // the batch of second-stream work now ends behind the pack (which reads the
   // frame's lists, keys and counters): its event is recorded again
-  if (on_side) HIP_TRY(c, hipEventRecord(c->ev_side[c->side_last], c->tstream));
+  if (on_side) {
+    if (c->side_expected[c->side_last]) {
+      c->side_expected[c->side_last] = ++c->side_serial;
+      hipLaunchKernelGGL(k_side_signal, dim3(1), dim3(64), 0, c->tstream, c->side_flag.p + c->side_last,
+                         c->side_expected[c->side_last]);
+      HIP_TRY(c, hipGetLastError());
+    } else {
+      HIP_TRY(c, hipEventRecord(c->ev_side[c->side_last], c->tstream));
+    }
+  }
   HIP_TRY(c, hipStreamWaitEvent(c->xstream, x.packed, 0));
   const uint64_t words = exchange_block_words(c->views, c->x_vis_cap, c->x_key_cap);
   if (c->comm) {
