@@ -634,7 +634,8 @@ def main() -> int:
                             "emission, outputs left in HBM; the 144-byte candidate rows of "
                             "application_build_world_payload are NOT in it (see dropin)",
             "streams": "scenes of 1M nodes and more with up to 8 views: scan, gather, sort and emission of a "
-                       "frame run on a second stream beside the next frame's transform and classify (more "
+                       "frame run on a second stream beside the next frame's transform and classify, enqueued by "
+                       "the context's worker thread (more "
                        "views: sort and emission only), so the dominant kernel's event time includes that "
                        "contention; VKRHIP_OVERLAP_TAIL=0 / VKRHIP_OVERLAP_SORT=0 keep one stream"
                        + ("; the exchange's pack follows the tail on the second stream, all-gather and merge "
