@@ -2079,12 +2079,13 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
 
 // Hierarchies below this size keep the transparent sort on the frame's stream.
 constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
-// ... and below this size the whole tail. A frame with its tail on the second stream
-// costs the host three stream-waits and an event more (about 36 us per frame against
-// 12), which sets the pace below roughly 40 us of device time per frame: 1M flat
-// nodes with one view 42.1 -> 40.7 us, 786K 36.1 -> 39.6 us; a 1M-node hierarchy of
-// depth 8 with five views 182 -> 122 us, 3M nodes 275 -> 206 us.
-constexpr uint64_t TAIL_MIN_NODES = 1000000ull;
+// ... and below this size the whole tail. With the worker thread enqueuing the tail a
+// frame costs the calling thread about 20 us and the worker about 32, which sets the
+// pace of frames the device finishes sooner; measured, the second stream wins or ties
+// from 128K nodes on (flat, one view: 262K nodes 23.9 us on one stream / 23.7 on
+// two, 786K 36.3 / 34.3, 1M 40.8 / 38.0; depth 8, five views: 131K 46.4 / 41.2, 524K
+// 119 / 90, 3M 275 / 206).
+constexpr uint64_t TAIL_MIN_NODES = 1ull << 17;
 
 // Whether the frame's transparent sort and emission go to the second stream,
 // beside the next frame's transform. They must then read nothing that transform
