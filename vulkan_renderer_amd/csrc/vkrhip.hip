@@ -965,6 +965,15 @@ int vkrhip_create(const vkrhip_config *config, vkrhip_ctx **out_ctx) {
   if (const char *env = std::getenv("VKRHIP_STAGED")) c->staged_compaction = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_OVERLAP_TAIL")) c->overlap_tail = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_TAIL_WORKER")) c->worker_mode = std::atoi(env);
+  // A gate kernel waits for a kernel of another queue, so the two must be able to run
+  // at the same time: a tool that serialises all kernels of the device (hardware
+  // counter collection, AMD_SERIALIZE_KERNEL) would leave every gate spinning until it
+  // gives up. Those that announce themselves in the environment switch the gates off.
+  for (const char *name : {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "ROCP_METRICS", "ROCP_INPUT",
+                           "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"}) {
+    const char *v = std::getenv(name);
+    if (v && *v && std::strcmp(v, "0") != 0) c->side_gate = 0;
+  }
   if (const char *env = std::getenv("VKRHIP_SIDE_GATE")) c->side_gate = std::atoi(env);
   if (const char *env = std::getenv("VKRHIP_XDEBUG")) c->xdebug = std::atoi(env);
   if (c->cfg.transparent_capacity == 0) c->cfg.transparent_capacity = c->cfg.max_candidates;
@@ -2086,6 +2095,7 @@ constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
 // two, 786K 36.3 / 34.3, 1M 40.8 / 38.0; depth 8, five views: 131K 46.4 / 41.2, 524K
 // 119 / 90, 3M 275 / 206).
 constexpr uint64_t TAIL_MIN_NODES = 1ull << 17;
+constexpr uint64_t TAIL_MIN_NODES_EVENTS = 1000000ull;
 
 // Whether the frame's transparent sort and emission go to the second stream,
 // beside the next frame's transform. They must then read nothing that transform
@@ -2125,7 +2135,10 @@ static bool tail_on_second_stream(const vkrhip_ctx *c, uint32_t stages, bool fus
   if (!fused || !second_stream_usable(c) || !(stages & VKRHIP_STAGE_TRANSPARENT)) return false;
   if (stages & (VKRHIP_STAGE_CANDIDATES | VKRHIP_STAGE_PACK | VKRHIP_STAGE_ENCODE)) return false;
   if (c->overlap_tail >= 2) return true;
-  return c->overlap_tail == 1 && c->overlap_sort != 0 && c->n_nodes >= TAIL_MIN_NODES &&
+  // (with events between the streams the wait packet costs small frames more than the
+  // second stream gives them: flat, one view, 524K nodes 29.8 us on one stream / 33.2 on two)
+  const uint64_t min_nodes = c->side_gate ? TAIL_MIN_NODES : TAIL_MIN_NODES_EVENTS;
+  return c->overlap_tail == 1 && c->overlap_sort != 0 && c->n_nodes >= min_nodes &&
          c->views <= TAIL_MAX_VIEWS;
 }
 
