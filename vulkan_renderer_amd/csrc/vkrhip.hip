@@ -2156,7 +2156,11 @@ static bool tail_on_second_stream(const vkrhip_ctx *c, uint32_t stages, bool fus
   if (c->overlap_tail >= 2) return true;
   // (with events between the streams the wait packet costs small frames more than the
   // second stream gives them: flat, one view, 524K nodes 29.8 us on one stream / 33.2 on two)
-  const uint64_t min_nodes = c->side_gate ? TAIL_MIN_NODES : TAIL_MIN_NODES_EVENTS;
+  // (with the multi-GPU exchange configured the host enqueues a pack, an all-gather and a
+  // merge per frame as well and small frames are bound by that: 1M nodes 58 us per frame
+  // on one stream, 78 on two)
+  const uint64_t min_nodes =
+      c->x_world ? OVERLAP_MIN_NODES : (c->side_gate ? TAIL_MIN_NODES : TAIL_MIN_NODES_EVENTS);
   return c->overlap_tail == 1 && c->overlap_sort != 0 && c->n_nodes >= min_nodes &&
          c->views <= TAIL_MAX_VIEWS;
 }
@@ -2367,7 +2371,11 @@ int vkrhip_frame(vkrhip_ctx *c, uint32_t stages) {
     // stream as a single thread would have left it.
     constexpr uint32_t kTailTimers = (1u << VKRHIP_TIMER_SCAN) | (1u << VKRHIP_TIMER_SCATTER) |
                                      (1u << VKRHIP_TIMER_SORT) | (1u << VKRHIP_TIMER_EMIT);
-    const bool to_worker = c->frame_tail && c->worker_mode != 0 && !(c->profiling & kTailTimers);
+    // (with the exchange configured vkrhip_exchange_run follows every frame and puts its
+    // pack behind the tail: it would only wait for the worker, 78 against 58 us per
+    // frame of 1M nodes)
+    const bool to_worker =
+        c->frame_tail && c->worker_mode != 0 && !(c->profiling & kTailTimers) && c->x_world == 0;
     if (!to_worker) TRY(worker_flush(c));
     if (c->frame_tail) {
       TRY(ensure_tail_buffers(c));
