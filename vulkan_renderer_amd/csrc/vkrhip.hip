@@ -3117,7 +3117,8 @@ void launch_exchange_merge(const ExchangeTables &t, uint32_t views, const uint32
   hipLaunchKernelGGL(k_exchange_plan, dim3(1), dim3(SCAN_BLOCK), 0, stream, a);
   // copy rows: enough blocks per descriptor to cover the largest possible range
   const unsigned rows = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vis_cap, 4096), 1), 64);
-  const unsigned key_blocks = (unsigned)ceil_div((uint64_t)world * key_cap, 256);
+  // (a block merges 256 keys of one run: every run may end in a block that is not full)
+  const unsigned key_blocks = (unsigned)ceil_div((uint64_t)world * key_cap, 256) + world;
   if (done)
     hipExtLaunchKernelGGL(k_exchange_apply, dim3(pairs * world * rows + key_blocks), dim3(256), 0, stream,
                           nullptr, done, 0, gathered_dev, (const uint64_t *)t.desc, pairs * world, rows,
