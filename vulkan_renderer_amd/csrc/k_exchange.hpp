@@ -76,8 +76,18 @@ __global__ __launch_bounds__(256) void k_exchange_pack(ExchangePackArgs a) {
     if (blockIdx.x == 0 && threadIdx.x < 8u)
       a.block[row * 8u + threadIdx.x] = a.states[row].execution_ranges[threadIdx.x >> 1][threadIdx.x & 1u];
     const uint32_t *src = a.visible + (uint64_t)row * a.visible_stride;
-    for (uint64_t i = first; i < count && start + i < a.vis_cap; i += step)
-      a.block[header + start + i] = src[i];
+    // (what of the list fits the block; eight loads in flight per thread)
+    const uint64_t n = min(count, (uint64_t)a.vis_cap - min(start, (uint64_t)a.vis_cap));
+    uint32_t *dst = a.block + header + start;
+    uint64_t i = first;
+    for (; i + 7u * step < n; i += 8u * step) {
+      uint32_t v[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; ++u) v[u] = src[i + u * step];
+#pragma unroll
+      for (uint32_t u = 0; u < 8u; ++u) dst[i + u * step] = v[u];
+    }
+    for (; i < n; i += step) dst[i] = src[i];
     return;
   }
   const uint32_t draws = a.have_keys ? a.counters[CNT_TRANSPARENT] : 0u;
