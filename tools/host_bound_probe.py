@@ -1,5 +1,6 @@
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from vulkan_renderer_amd import _native as N
 torch.cuda.set_device(0)
