@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Frames of the 16M-node hierarchy in which a tenth of the level-2 subtrees moves:
+what the deferred dirty propagation on the device costs against marking every
+moved node from the host (same set of updated nodes either way)."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from vulkan_renderer_amd import _native as N
 torch.cuda.set_device(0)

@@ -1,5 +1,9 @@
-import sys, time, os
+#!/usr/bin/env python3
+"""Is the calling thread the bound of the 1M-node frame loop? Enqueue time per
+frame (the loop without the final wait) against total time per frame."""
 import os
+import sys
+import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from vulkan_renderer_amd import _native as N
