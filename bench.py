@@ -633,7 +633,7 @@ def main() -> int:
             "timed_stages": "transform + multi-view cull + compaction + transparent key sort and draw "
                             "emission, outputs left in HBM; the 144-byte candidate rows of "
                             "application_build_world_payload are NOT in it (see dropin)",
-            "streams": "scenes of 128K nodes and more with up to 8 views: scan, gather, sort and emission of a "
+            "streams": "scenes of 16K nodes and more with up to 8 views: scan, gather, sort and emission of a "
                        "frame run on a second stream beside the next frame's transform and classify, enqueued by "
                        "the context's worker thread (more "
                        "views: sort and emission only), so the dominant kernel's event time includes that "

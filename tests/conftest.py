@@ -81,7 +81,7 @@ def tail_mode(request, monkeypatch):
     """Runs a test several times: as the library decides by itself (small scenes keep
     the whole frame on one stream) and with VKRHIP_OVERLAP_TAIL=2, where every frame
     the fused kernel serves puts scan, gather, sort and emission on the second stream
-    and the next frame starts right behind the classify (what scenes of 128K nodes and
+    and the next frame starts right behind the classify (what scenes of 16K nodes and
     more do by default) - with the tail enqueued by the context's worker thread and
     the streams ordered by signal and gate kernels (the default), with the calling
     thread enqueuing everything (VKRHIP_TAIL_WORKER=0), and with events between the

@@ -2115,13 +2115,13 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
 
 // Hierarchies below this size keep the transparent sort on the frame's stream.
 constexpr uint64_t OVERLAP_MIN_NODES = 4ull << 20;
-// ... and below this size the whole tail. With the worker thread enqueuing the tail a
-// frame costs the calling thread about 20 us and the worker about 32, which sets the
-// pace of frames the device finishes sooner; measured, the second stream wins or ties
-// from 128K nodes on (flat, one view: 262K nodes 23.9 us on one stream / 23.7 on
-// two, 786K 36.3 / 34.3, 1M 40.8 / 38.0; depth 8, five views: 131K 46.4 / 41.2, 524K
-// 119 / 90, 3M 275 / 206).
-constexpr uint64_t TAIL_MIN_NODES = 1ull << 17;
+// ... and below this size the whole tail. With the worker thread enqueuing the tail and
+// kernels instead of events between the streams a frame costs the calling thread and
+// the worker about 11 us each, and the second stream wins at every size measured (flat,
+// one view: 20K nodes 25.3 us on one stream / 20.0 on two, 131K 24.5 / 18.4, 1M 40.8 /
+// 35.8; depth 8, five views: 20K 37.3 / 29.7, 65K 52.4 / 36.2, 524K 119 / 90, 3M 275 /
+// 206).
+constexpr uint64_t TAIL_MIN_NODES = 1ull << 14;
 constexpr uint64_t TAIL_MIN_NODES_EVENTS = 1000000ull;
 
 // Whether the frame's transparent sort and emission go to the second stream,
