@@ -328,6 +328,26 @@ def test_large_transparent_sort(oracle):
         compare_frame(hs, ref, sc)
 
 
+def test_rank_sort_above_eight_thousand(oracle):
+    """Between 8 192 and about 16 000 visible blend rows the rows are still ranked by
+    counting (one launch) once the host has seen the count: the first frame sorts them
+    with the multi-pass kernels, the second by ranking, both like the oracle."""
+    synth = _synth()
+    sc = synth.flat_scene(180000, seed=21, blend_fraction=1.0)
+    sc.pos[::5, :3] = sc.pos[1, :3]            # a fifth of the rows share one depth
+    vs = synth.camera_views(far=4000.0, fov_deg=70.0)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    assert 9000 < ref["payload"]["draws"].shape[0] < 15000
+    with hip_scene_for(sc, 1) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame()
+        compare_frame(hs, ref, sc, check_transform=False)
+
+
 def test_separate_stages(oracle):
     """Transform in one frame call, cull + sort in another: the stand-alone
     classify kernel with the identity candidate->node mapping."""

@@ -618,7 +618,10 @@ __global__ __launch_bounds__(256) void k_emit_transparent(EmitArgs a) {
 // the count; it is correct, but runs at one CU's bandwidth.
 constexpr int RANK_BLOCK_KEYS = 8;
 constexpr int RANK_LOADS = 4;  // sweep loads in flight per wave
-constexpr uint32_t RANK_LIMIT = SMALL_KEYS;
+// (ranking is quadratic, the radix path five dependent launches: measured with the tail
+// beside the next frame, 7 K keys 102 -> 67 us per frame and 14.6 K keys 132 -> 113 us by
+// ranking, 21 K keys 161 -> 168 us - the paths cross at about 16 K keys)
+constexpr uint32_t RANK_LIMIT = 20480;
 
 __global__ __launch_bounds__(SMALL_THREADS) void k_rank_emit(EmitArgs a, uint64_t *keys,
                                                              uint64_t *scratch) {
