@@ -1080,6 +1080,10 @@ struct GatherArgs {
   uint64_t candidates;      // n > 0
   uint32_t views;
   uint32_t partition_capacity;
+  // k_gather: waves per segment. 1: a wave walks all views of its segment, four per
+  // request; `views`: one wave per (segment, view) - scenes of few segments, where the
+  // launch is as long as one wave's chain of views (256 segments, five views: 27 us).
+  uint32_t view_parts;
 };
 
 constexpr int GATHER_BLOCK = 256;  // four waves, one segment each
@@ -1184,7 +1188,10 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
     for (uint32_t v = t; v < a.views; v += GATHER_BLOCK)
       a.states[v] = prefix_state(a.row_totals + v * 4u, a.partition_capacity, a.visible_stride);
 
-  const uint64_t seg = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
+  const uint32_t parts = a.view_parts;  // >= 1
+  const uint64_t wave_index = (uint64_t)blockIdx.x * (GATHER_BLOCK / 64) + wave;
+  const uint64_t seg = wave_index / parts;
+  const uint32_t part = (uint32_t)(wave_index % parts);
   if (seg >= a.segments) return;  // wave-uniform; no block-wide barrier below
   const unsigned long long *record = a.seg_masks + seg * seg_record_words(a.views);
   // (the same address, known to be the same for the whole wave: scalar loads)
@@ -1210,7 +1217,8 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
     for (uint32_t b = 0; b < 4u; ++b) c.total[b] = a.row_totals[(c.row & ~3u) + b];
     return c;
   };
-  Chunk cur = request(0u);
+  const uint32_t view_step = parts > 1u ? parts : 4u;
+  Chunk cur = request(parts > 1u ? part : 0u);
   const uint32_t origin = a.seg_first[seg];
   const unsigned long long in_bucket = record[CULL_SLOTS * a.views + slot * 4u + bucket];
   // (a set bit always stands for a candidate; the clamp keeps the loads inside the
@@ -1220,13 +1228,14 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
     return a.remap ? a.remap[min(candidate, last_candidate)] : (uint32_t)(a.index_base + candidate);
   };
 
-  gather_blend_rows<1>(a, lane < (uint32_t)CULL_SLOTS ? record[CULL_SLOTS * (a.views + 4u) + lane] : 0ull,
-                       [&](uint32_t) { return origin; },
-                       [&](uint32_t) { return a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg]; });
+  if (part == 0u)  // wave-uniform
+    gather_blend_rows<1>(a, lane < (uint32_t)CULL_SLOTS ? record[CULL_SLOTS * (a.views + 4u) + lane] : 0ull,
+                         [&](uint32_t) { return origin; },
+                         [&](uint32_t) { return a.seg_offsets[(uint64_t)vrows * a.seg_stride + seg]; });
 
-  for (uint32_t v0 = 0; v0 < a.views; v0 += 4u) {
+  for (uint32_t v0 = parts > 1u ? part : 0u; v0 < a.views; v0 += view_step) {
     const Chunk c = cur;
-    if (v0 + 4u < a.views) cur = request(v0 + 4u);  // in flight while this chunk is written
+    if (v0 + view_step < a.views) cur = request(v0 + view_step);  // in flight while this chunk is written
     // where the row's bucket starts inside its view's list and how much of it is
     // kept (as prefix_state lays the buckets out)
     uint32_t row_start = 0u, row_kept = 0u;
@@ -1237,7 +1246,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(GatherArgs a) {
       if (b < (c.row & 3u)) row_start += room;
     }
 
-    const uint32_t in_chunk = min(4u, a.views - v0);
+    const uint32_t in_chunk = parts > 1u ? 1u : min(4u, a.views - v0);
     for (uint32_t j = 0; j < in_chunk; ++j) {  // wave-uniform
       const unsigned long long mine = shfl64(c.masks, j * 16u + slot) & in_bucket;
       const uint32_t count = (uint32_t)__popcll(mine);

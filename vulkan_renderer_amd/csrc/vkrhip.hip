@@ -811,6 +811,7 @@ constexpr uint64_t kStreamingFootprint = 300ull << 20;  // bytes (measured cross
 // 552 -> 550 us), all levels in one launch lose (632 us).
 constexpr uint32_t kTopMaxTiles = 3072;
 constexpr uint32_t kTopMaxAncestors = TOP_MAX_ANCESTORS;
+constexpr uint64_t kGatherSplitSegments = 4096;  // scenes up to this many segments gather with a wave per (segment, view)
 constexpr uint64_t kStepsMinNodes = 1ull << 20;  // levels below this keep their parent indices
 constexpr uint32_t kTopMaxSteps = 24;
 
@@ -2105,7 +2106,11 @@ static int launch_compaction(vkrhip_ctx *c, bool set_aside, hipStream_t on) {
     g.views = c->views;
     g.partition_capacity = c->cfg.partition_capacity;
     // (a wave of k_gather takes one segment, a wave of k_place PLACE_SEGS)
-    const unsigned grid = (unsigned)ceil_div(segments, (GATHER_BLOCK / 64) * (c->frame_staged ? PLACE_SEGS : 1u));
+    // (few segments: a wave per (segment, view), see GatherArgs::view_parts)
+    const bool plain_gather = !c->frame_staged && c->views <= GATHER_MANY_VIEWS;
+    g.view_parts = plain_gather && c->views > 1u && segments <= kGatherSplitSegments ? c->views : 1u;
+    const unsigned grid = (unsigned)ceil_div(segments * g.view_parts,
+                                             (GATHER_BLOCK / 64) * (c->frame_staged ? PLACE_SEGS : 1u));
     launch_on(c, on, c->frame_staged ? k_place : (c->views > GATHER_MANY_VIEWS ? k_gather_many : k_gather),
               dim3(grid), dim3(GATHER_BLOCK), 0, g);
     HIP_TRY(c, hipGetLastError());
