@@ -180,3 +180,26 @@ def test_large_level_parent_forms(oracle, shape):
         hs.frame()
         compare_frame(hs, ref, sc, check_transform=False)
         assert hs.frame_info().nodes_updated == sc.n
+
+
+@pytest.mark.parametrize("n", [524288, 1000000])
+def test_hierarchy_whose_last_level_has_a_low_fan_out(oracle, n):
+    """Depth-8 hierarchies whose last level is smaller than (524 288 nodes) or less than
+    three times (1M nodes) the level above it: blocks of the merged top-level launch
+    would have more ancestors than its table holds, so the plan is rebuilt with fewer
+    levels or with shorter blocks."""
+    synth = _synth()
+    sc = synth.deep_scene(n, depth=8, seed=9)
+    sizes = np.diff(sc.level_offsets.astype(np.int64))
+    assert sizes[-1] < 3 * sizes[-2]
+    vs = synth.camera_views(cascades=2)
+    planes, required = view_set(vs)
+    ref = oracle_frame(oracle, sc, planes, required, vs.view, vs.projection)
+    with hip_scene_for(sc, planes.shape[0]) as hs:
+        hs.set_views(planes, required, vs.view)
+        hs.frame()
+        compare_frame(hs, ref, sc)
+        hs.mark_all(DIRTY_WORLD)
+        hs.frame()
+        compare_frame(hs, ref, sc, check_transform=False)
+        assert hs.frame_info().nodes_updated == sc.n
